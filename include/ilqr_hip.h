@@ -1,0 +1,182 @@
+/*
+ * C ABI of the MI355X batched iLQR library (libilqr_hip.so).
+ *
+ * The reference (ZhengYi0310/ilqr) is pure Python: its "FFI" for this path is
+ * the set of Python methods cited beside each entry point below.  Every entry
+ * point takes plain pointers and sizes only.  Unless stated otherwise pointers
+ * are DEVICE pointers to fp64 / int32 arrays owned by the caller, the call is
+ * asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ * stream), re-entrant (all state lives in caller buffers) and returns ILQR_OK
+ * or a negative ilqr_status; per-problem numerical outcomes are written to
+ * output arrays, never to the return code.
+ *
+ * Layouts.  "ref" layout is the reference's own, batch outermost:
+ *   x0 [B,n]  us [B,T,m]  xs [B,T+1,n]  k [B,T,m]  K [B,T,m,n].
+ * "bm" (batch-minor) layout is what the kernels stream: the per-problem array
+ * is flattened row-major to R numbers and stored as [R, ld] with the problem
+ * index innermost, ld >= B (ilqr_bm_ld(B) rounds B up to a multiple of 64) so
+ * that the 64 lanes of a wavefront read 64 consecutive doubles.
+ */
+#ifndef ILQR_HIP_H
+#define ILQR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ilqr_status {
+    ILQR_OK = 0,
+    ILQR_ERR_ARG = -1,         /* null pointer, non-positive size, ld < B ... */
+    ILQR_ERR_UNSUPPORTED = -2, /* model / dimension / option without a kernel */
+    ILQR_ERR_HIP = -3,         /* a HIP runtime call failed */
+    ILQR_ERR_WORKSPACE = -4    /* workspace too small */
+} ilqr_status;
+
+enum { ILQR_MODEL_CARTPOLE = 0 };
+enum { ILQR_COST_QR = 0 };
+
+/* Per-problem status written by ilqr_solve_batched (update_u's three exits,
+ * ilqr_core.py:284, :331/:347, :337-339). */
+enum { ILQR_RAN_OUT = 0, ILQR_CONVERGED = 1, ILQR_MU_MAX = 2 };
+
+/* Model + cost + bounds shared by every problem of a batch.  All pointers in
+ * this struct are HOST pointers; the (small) arrays are copied into kernel
+ * arguments by each call.
+ *   cartpole: CartPoleDynamics(dt, max_control, mc, mp, l, g), ilqr/cartpole.py:8;
+ *             n = 5 ([x, x', sin, cos, theta']), m = 1.
+ *   QRCost(Q, R, Q_terminal, x_goal, u_goal), ilqr/ilqr_cost.py:490-530. */
+typedef struct ilqr_model {
+    int32_t model;         /* ILQR_MODEL_* */
+    int32_t n, m, T;       /* state dim, control dim, horizon N */
+    int32_t cost_kind;     /* ILQR_COST_* */
+    int32_t control_limit; /* iLQR(control_limit=...), ilqr_core.py:32; only 1 is supported */
+    double dt, mc, mp, l, g;
+    const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] row-major */
+    const double *x_goal, *u_goal;    /* [n], [m] */
+    const double *lower, *upper;      /* dynamics.lower_bound / upper_bound, [m] */
+} ilqr_model;
+
+/* update_u keyword arguments (ilqr_core.py:241), the solver constants of
+ * iLQR.__init__ (:58-62) and the boxQP options the solver passes (:154-155). */
+typedef struct ilqr_opts {
+    int32_t max_iter; /* n_interations */
+    int32_t n_alpha;  /* line_search_steps, <= 32 */
+    const double* alphas; /* HOST [n_alpha]: 1.1 ** (-arange(n_alpha) ** 2), :267 */
+    double tol, scale;
+    double mu_min, mu_max, delta0;
+    int32_t qp_max_iter;
+    int32_t pad_;
+    double qp_min_grad, qp_min_rel_improve, qp_step_dec, qp_min_step, qp_armijo;
+} ilqr_opts;
+
+/* Optional per-iteration record of ilqr_solve_batched, each array [max_iter, B]
+ * (iteration outermost), any pointer may be NULL.  It carries what update_u's
+ * on_iteration callback sees (ilqr_core.py:342-345) plus the counters needed
+ * to compare line-search and boxQP behaviour. */
+typedef struct ilqr_trace {
+    double* J;             /* J_opt after the iteration */
+    int32_t* accepted;     /* 0/1; -1 where the problem was already finished */
+    int32_t* alpha_idx;    /* index of the alpha at which the line search ended (n_alpha = ran out) */
+    double* mu;
+    double* delta;
+    int32_t* qp_iter;      /* boxQP search steps summed over the T steps of the backward pass */
+    int32_t* qp_backtrack; /* Armijo step reductions summed over the backward pass */
+    int32_t* n_clamped;    /* steps of the backward pass with a clamped control */
+    int32_t* stopped_at;   /* step at which Q_uu was not PD (ilqr_core.py:137-140), -1 if none */
+} ilqr_trace;
+
+int ilqr_version(void);
+const char* ilqr_status_string(int status);
+
+/* Leading dimension the library recommends for B problems (B rounded up to 64). */
+int64_t ilqr_bm_ld(int64_t B);
+
+/* ref [B, R] -> bm [R, ld] and back.  No counterpart in the reference. */
+int ilqr_pack_bm(const double* src, double* dst_bm, int64_t B, int64_t R, int64_t ld, void* stream);
+int ilqr_unpack_bm(const double* src_bm, double* dst, int64_t B, int64_t R, int64_t ld, void* stream);
+
+/* iLQR._dynamics_rollout (ilqr_core.py:69-83) + iLQR._trajectory_cost (:230-239).
+ * x0_bm [n, ld], us_bm [T*m, ld] -> xs_bm [(T+1)*n, ld], J [B]. */
+int ilqr_rollout_cost_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* x0_bm,
+                         const double* us_bm, double* xs_bm, double* J, void* stream);
+
+/* Dynamics.f_x / f_u (ilqr_dynamics.py:498-524; Theano Jacobian of diff_utils.py:28-37)
+ * and Cost.l_x, l_u, l_xx, l_uu, l_ux (ilqr_cost.py:555-632) for every (problem, step),
+ * plus the terminal l_x, l_xx: the tensors _compute_Q_terms (ilqr_core.py:189-198) asks
+ * for, written as batch-minor streams:
+ *   fx [T*n*n, ld]  fu [T*n*m, ld]  lx [T*n, ld]  lu [T*m, ld]  lxx [T*n*n, ld]
+ *   luu [T*m*m, ld]  lux [T*m*n, ld]  lxT [n, ld]  lxxT [n*n, ld]. */
+typedef struct ilqr_deriv_bm {
+    double *fx, *fu, *lx, *lu, *lxx, *luu, *lux, *lxT, *lxxT;
+} ilqr_deriv_bm_t;
+int ilqr_deriv_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* xs_bm,
+                  const double* us_bm, const ilqr_deriv_bm_t* out, void* stream);
+
+/* iLQR._backward_pass + _compute_Q_terms (ilqr_core.py:109-228) with boxQP inside
+ * (ilqr_boxQP.py:9-186), one problem per lane.
+ *   mu [B]; deriv: NULL = evaluate derivatives in the kernel, else read the
+ *   streams written by ilqr_deriv_bm.
+ *   -> k_bm [T*m, ld], K_bm [T*m*n, ld] (zero where the sweep did not reach),
+ *      dJ [2, ld] (Delta_J1, Delta_J2),
+ *      info [4, ld] int32: stopped_at, qp_iter, qp_backtrack, n_clamped,
+ *      qp_result_bm [T, ld] (boxQP result code per step, -100 = not reached; may be NULL),
+ *      free_bm [T*m, ld] (boxQP free mask per step; may be NULL). */
+int ilqr_backward_bm(const ilqr_model* model, const ilqr_opts* opts, int64_t B, int64_t ld,
+                     const double* xs_bm, const double* us_bm, const double* mu,
+                     const ilqr_deriv_bm_t* deriv, double* k_bm, double* K_bm, double* dJ,
+                     int32_t* info, int32_t* qp_result_bm, int32_t* free_bm, void* stream);
+
+/* iLQR._forward_pass (ilqr_core.py:85-107) + _trajectory_cost for every
+ * (problem, alpha) in parallel: alphas HOST [n_alpha] -> J_new [n_alpha, ld];
+ * xs_new_bm [n_alpha, (T+1)*n, ld] and us_new_bm [n_alpha, T*m, ld] are written
+ * when not NULL. */
+int ilqr_forward_ls_bm(const ilqr_model* model, int64_t B, int64_t ld, int32_t n_alpha,
+                       const double* alphas, const double* xs_bm, const double* us_bm,
+                       const double* k_bm, const double* K_bm, double* J_new, double* xs_new_bm,
+                       double* us_new_bm, void* stream);
+
+/* boxQP(H, g, lower, upper, x0, **opts) (ilqr_boxQP.py:9-186) for B independent QPs,
+ * ref layout: H [B,m,m], g/lower/upper/x0 [B,m] (x0 may be NULL: start at the box
+ * centre, :44-46), m <= 8.  Only the qp_* fields of opts are read.
+ *   -> x [B,m], result [B] (codes of :173-180), Hff [B,m,m] (free-subspace Cholesky
+ *      factor in the leading hff_dim x hff_dim block, row stride m; all ones if no
+ *      factorisation happened, :36), hff_dim [B], free_mask [B,m],
+ *      counters [B,3] = search steps, factorisations, Armijo reductions. */
+int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, const double* lower,
+                       const double* upper, const double* x0, const ilqr_opts* opts, double* x,
+                       int32_t* result, double* Hff, int32_t* hff_dim, int32_t* free_mask,
+                       int32_t* counters, void* stream);
+
+/* iLQR.update_u (ilqr_core.py:241-399) for B problems, entirely on the device: one
+ * launch runs every problem to its own termination (converged, mu >= mu_max or
+ * max_iter iterations); the host is not involved per iteration.  ref layout.
+ *   in : x0 [B,n], us_init [B,T,m]
+ *   io : delta [B]   (the solver's delta_, persists across calls; 2.0 at construction)
+ *        k [B,T,m], K [B,T,m,n] (the solver's k_/K_; zeros at construction)
+ *   out: xs [B,T+1,n], us [B,T,m], J [B], mu [B], iters [B], status [B] (ILQR_RAN_OUT..)
+ *   trace: NULL or device arrays as described at ilqr_trace.
+ *   workspace: device buffer of at least ilqr_solve_workspace_bytes(model, B). */
+size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B);
+int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                       const double* us_init, double* delta, double* k, double* K, double* xs,
+                       double* us, double* J, double* mu, int32_t* iters, int32_t* status,
+                       const ilqr_trace* trace, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* CartPoleContinuousEnv._state_eq (ilqr/cartpole_gym.py:60-72), the plant the MPC
+ * example steps: st [B,4] = [x, x', theta, theta'], u [B] -> out [B,4].
+ * par HOST [5] = gravity, masscart, masspole, length, tau. */
+int ilqr_cartpole_plant_step(int64_t B, const double* par, const double* st, const double* u,
+                             double* out, void* stream);
+
+/* Test hook: the library's own sin/cos/atan2 on arrays (a, b) -> sin a, cos a, atan2(a, b). */
+int ilqr_detmath(int64_t n, const double* a, const double* b, double* sin_a, double* cos_a,
+                 double* atan2_ab, double* sqrt_abs_a, double* a_over_b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILQR_HIP_H */
