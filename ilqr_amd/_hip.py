@@ -1,0 +1,323 @@
+"""ctypes binding of libilqr_hip.so (the C ABI declared in include/ilqr_hip.h).
+
+PyTorch is used for device memory and streams only: every function here takes
+contiguous fp64 / int32 ROCm tensors and passes their data_ptr() through the C
+ABI.  There is no CPU fallback: without the shared library or without a GPU
+these calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libilqr_hip.so")
+
+ILQR_OK = 0
+MODEL_CARTPOLE = 0
+COST_QR = 0
+STATUS_RAN_OUT, STATUS_CONVERGED, STATUS_MU_MAX = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+
+class ModelC(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32),
+        ("cost_kind", C.c_int32), ("control_limit", C.c_int32),
+        ("dt", C.c_double), ("mc", C.c_double), ("mp", C.c_double), ("l", C.c_double), ("g", C.c_double),
+        ("Q", _dp), ("R", _dp), ("Q_terminal", _dp), ("x_goal", _dp), ("u_goal", _dp),
+        ("lower", _dp), ("upper", _dp),
+    ]
+
+
+class OptsC(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int32), ("n_alpha", C.c_int32), ("alphas", _dp),
+        ("tol", C.c_double), ("scale", C.c_double),
+        ("mu_min", C.c_double), ("mu_max", C.c_double), ("delta0", C.c_double),
+        ("qp_max_iter", C.c_int32), ("pad_", C.c_int32),
+        ("qp_min_grad", C.c_double), ("qp_min_rel_improve", C.c_double), ("qp_step_dec", C.c_double),
+        ("qp_min_step", C.c_double), ("qp_armijo", C.c_double),
+    ]
+
+
+class TraceC(C.Structure):
+    _fields_ = [(name, _vp) for name in
+                ("J", "accepted", "alpha_idx", "mu", "delta", "qp_iter", "qp_backtrack", "n_clamped",
+                 "stopped_at")]
+
+
+class DerivC(C.Structure):
+    _fields_ = [(name, _vp) for name in ("fx", "fu", "lx", "lu", "lxx", "luu", "lux", "lxT", "lxxT")]
+
+
+EXPORTS = (
+    "ilqr_version", "ilqr_status_string", "ilqr_bm_ld", "ilqr_pack_bm", "ilqr_unpack_bm",
+    "ilqr_rollout_cost_bm", "ilqr_deriv_bm", "ilqr_backward_bm", "ilqr_forward_ls_bm",
+    "ilqr_boxqp_batched", "ilqr_solve_workspace_bytes", "ilqr_solve_batched",
+    "ilqr_cartpole_plant_step", "ilqr_detmath",
+)
+
+_lib = None
+
+
+class IlqrHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libilqr_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IlqrHipError("%s is missing: build it with `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ilqr_status_string.restype = C.c_char_p
+        L.ilqr_bm_ld.restype = C.c_int64
+        L.ilqr_bm_ld.argtypes = [C.c_int64]
+        L.ilqr_solve_workspace_bytes.restype = C.c_size_t
+        L.ilqr_solve_workspace_bytes.argtypes = [C.POINTER(ModelC), C.c_int64]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != ILQR_OK:
+        raise IlqrHipError("libilqr_hip: %s (%d)" % (lib().ilqr_status_string(rc).decode(), rc))
+
+
+def _host(a, shape):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))
+
+
+class Model:
+    """Host description of the problem family (model + cost + bounds)."""
+
+    def __init__(self, T, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
+                 dt=0.05, mc=1.0, mp=0.1, l=1.0, g=9.8, n=5, m=1, model=MODEL_CARTPOLE, control_limit=True):
+        self.n, self.m, self.T = int(n), int(m), int(T)
+        self.Q = _host(Q, (n, n))
+        self.R = _host(R, (m, m))
+        self.Qt = self.Q if Q_terminal is None else _host(Q_terminal, (n, n))
+        self.x_goal = _host(np.zeros(n) if x_goal is None else x_goal, (n,))
+        self.u_goal = _host(np.zeros(m) if u_goal is None else u_goal, (m,))
+        self.lower = _host(lower, (m,))
+        self.upper = _host(upper, (m,))
+        c = ModelC()
+        c.model, c.n, c.m, c.T = model, n, m, T
+        c.cost_kind, c.control_limit = COST_QR, int(bool(control_limit))
+        c.dt, c.mc, c.mp, c.l, c.g = dt, mc, mp, l, g
+        for name, arr in (("Q", self.Q), ("R", self.R), ("Q_terminal", self.Qt), ("x_goal", self.x_goal),
+                          ("u_goal", self.u_goal), ("lower", self.lower), ("upper", self.upper)):
+            setattr(c, name, arr.ctypes.data_as(_dp))
+        self.c = c
+
+
+class Opts:
+    def __init__(self, max_iter=200, tol=1e-4, line_search_steps=30, scale=0.1, mu_min=1e-6, mu_max=1e10,
+                 delta0=2.0, qp_max_iter=100, qp_min_grad=1e-8, qp_min_rel_improve=1e-8, qp_step_dec=0.9,
+                 qp_min_step=1e-22, qp_armijo=0.1, alphas=None):
+        # the reference's schedule, ilqr_core.py:267
+        self.alphas = _host(1.1 ** (-np.arange(line_search_steps) ** 2) if alphas is None else alphas, (-1,))
+        o = OptsC()
+        o.max_iter, o.n_alpha = int(max_iter), len(self.alphas)
+        o.alphas = self.alphas.ctypes.data_as(_dp)
+        o.tol, o.scale = tol, scale
+        o.mu_min, o.mu_max, o.delta0 = mu_min, mu_max, delta0
+        o.qp_max_iter = qp_max_iter
+        o.qp_min_grad, o.qp_min_rel_improve, o.qp_step_dec = qp_min_grad, qp_min_rel_improve, qp_step_dec
+        o.qp_min_step, o.qp_armijo = qp_min_step, qp_armijo
+        self.c = o
+        self.max_iter = int(max_iter)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype):
+    import torch
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+def bm_ld(B):
+    return int(lib().ilqr_bm_ld(int(B)))
+
+
+def pack_bm(src, ld=None):
+    """ref [B, ...] -> bm [R, ld] (R = product of the trailing dims)."""
+    import torch
+    B = src.shape[0]
+    src = _req(src.reshape(B, -1).contiguous(), torch.float64)
+    R = src.shape[1]
+    ld = bm_ld(B) if ld is None else ld
+    dst = torch.zeros((R, ld), dtype=torch.float64, device=src.device)
+    check(lib().ilqr_pack_bm(_ptr(src), _ptr(dst), C.c_int64(B), C.c_int64(R), C.c_int64(ld), _stream()))
+    return dst
+
+
+def unpack_bm(src_bm, B, shape):
+    import torch
+    src_bm = _req(src_bm, torch.float64)
+    R, ld = src_bm.shape
+    dst = torch.empty((B, R), dtype=torch.float64, device=src_bm.device)
+    check(lib().ilqr_unpack_bm(_ptr(src_bm), _ptr(dst), C.c_int64(B), C.c_int64(R), C.c_int64(ld), _stream()))
+    return dst.reshape((B,) + tuple(shape))
+
+
+def rollout_cost_bm(M, B, x0_bm, us_bm):
+    import torch
+    ld = x0_bm.shape[1]
+    xs = torch.empty(((M.T + 1) * M.n, ld), dtype=torch.float64, device=x0_bm.device)
+    J = torch.empty(B, dtype=torch.float64, device=x0_bm.device)
+    check(lib().ilqr_rollout_cost_bm(C.byref(M.c), C.c_int64(B), C.c_int64(ld), _ptr(x0_bm), _ptr(us_bm),
+                                     _ptr(xs), _ptr(J), _stream()))
+    return xs, J
+
+
+def deriv_bm(M, B, xs_bm, us_bm):
+    import torch
+    ld = xs_bm.shape[1]
+    T, n, m = M.T, M.n, M.m
+    rows = dict(fx=T * n * n, fu=T * n * m, lx=T * n, lu=T * m, lxx=T * n * n, luu=T * m * m, lux=T * m * n,
+                lxT=n, lxxT=n * n)
+    out = {k: torch.empty((r, ld), dtype=torch.float64, device=xs_bm.device) for k, r in rows.items()}
+    d = DerivC()
+    for k in rows:
+        setattr(d, k, out[k].data_ptr())
+    check(lib().ilqr_deriv_bm(C.byref(M.c), C.c_int64(B), C.c_int64(ld), _ptr(xs_bm), _ptr(us_bm), C.byref(d),
+                              _stream()))
+    return out
+
+
+def backward_bm(M, O, B, xs_bm, us_bm, mu, want_masks=True):
+    import torch
+    ld = xs_bm.shape[1]
+    dev = xs_bm.device
+    k = torch.empty((M.T * M.m, ld), dtype=torch.float64, device=dev)
+    K = torch.empty((M.T * M.m * M.n, ld), dtype=torch.float64, device=dev)
+    dJ = torch.zeros((2, ld), dtype=torch.float64, device=dev)
+    info = torch.zeros((5, ld), dtype=torch.int32, device=dev)
+    qres = torch.full((M.T, ld), -100, dtype=torch.int32, device=dev) if want_masks else None
+    free = torch.zeros((M.T * M.m, ld), dtype=torch.int32, device=dev) if want_masks else None
+    check(lib().ilqr_backward_bm(C.byref(M.c), C.byref(O.c), C.c_int64(B), C.c_int64(ld), _ptr(xs_bm),
+                                 _ptr(us_bm), _ptr(_req(mu, torch.float64)), None, _ptr(k), _ptr(K), _ptr(dJ),
+                                 _ptr(info), _ptr(qres), _ptr(free), _stream()))
+    return dict(k=k, K=K, dJ=dJ, info=info, qp_result=qres, free=free)
+
+
+def forward_ls_bm(M, B, alphas, xs_bm, us_bm, k_bm, K_bm, want_traj=False):
+    import torch
+    ld = xs_bm.shape[1]
+    dev = xs_bm.device
+    al = _host(alphas, (-1,))
+    nA = len(al)
+    J = torch.empty((nA, ld), dtype=torch.float64, device=dev)
+    xs_new = torch.empty((nA, (M.T + 1) * M.n, ld), dtype=torch.float64, device=dev) if want_traj else None
+    us_new = torch.empty((nA, M.T * M.m, ld), dtype=torch.float64, device=dev) if want_traj else None
+    check(lib().ilqr_forward_ls_bm(C.byref(M.c), C.c_int64(B), C.c_int64(ld), C.c_int32(nA),
+                                   al.ctypes.data_as(_dp), _ptr(xs_bm), _ptr(us_bm), _ptr(k_bm), _ptr(K_bm),
+                                   _ptr(J), _ptr(xs_new), _ptr(us_new), _stream()))
+    return J, xs_new, us_new
+
+
+def solve_workspace_bytes(M, B):
+    return int(lib().ilqr_solve_workspace_bytes(C.byref(M.c), C.c_int64(B)))
+
+
+TRACE_FIELDS = (("J", "f8"), ("accepted", "i4"), ("alpha_idx", "i4"), ("mu", "f8"), ("delta", "f8"),
+                ("qp_iter", "i4"), ("qp_backtrack", "i4"), ("n_clamped", "i4"), ("stopped_at", "i4"))
+
+
+def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, out=None):
+    """ilqr_solve_batched on ref-layout tensors.  Returns a dict of device tensors.
+
+    ``out`` may carry preallocated result tensors (keys xs, us, J, mu, iters,
+    status) and ``workspace`` a uint8 tensor, so that a timed loop allocates nothing.
+    """
+    import torch
+    B = x0.shape[0]
+    dev = x0.device
+    T, n, m = M.T, M.n, M.m
+    x0 = _req(x0.reshape(B, n), torch.float64)
+    us_init = _req(us_init.reshape(B, T, m), torch.float64)
+    delta = torch.full((B,), 2.0, dtype=torch.float64, device=dev) if delta is None else delta
+    k = torch.zeros((B, T, m), dtype=torch.float64, device=dev) if k is None else k
+    K = torch.zeros((B, T, m, n), dtype=torch.float64, device=dev) if K is None else K
+    out = {} if out is None else out
+    res = dict(
+        xs=out.get("xs", None), us=out.get("us", None), J=out.get("J", None), mu=out.get("mu", None),
+        iters=out.get("iters", None), status=out.get("status", None))
+    if res["xs"] is None:
+        res["xs"] = torch.empty((B, T + 1, n), dtype=torch.float64, device=dev)
+        res["us"] = torch.empty((B, T, m), dtype=torch.float64, device=dev)
+        res["J"] = torch.empty(B, dtype=torch.float64, device=dev)
+        res["mu"] = torch.empty(B, dtype=torch.float64, device=dev)
+        res["iters"] = torch.empty(B, dtype=torch.int32, device=dev)
+        res["status"] = torch.empty(B, dtype=torch.int32, device=dev)
+    need = solve_workspace_bytes(M, B)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    tr_c, tr = None, None
+    if trace:
+        tr, tr_c = {}, TraceC()
+        for name, dt in TRACE_FIELDS:
+            if dt == "f8":
+                t = torch.full((O.max_iter, B), float("nan"), dtype=torch.float64, device=dev)
+            else:
+                t = torch.full((O.max_iter, B), -1, dtype=torch.int32, device=dev)
+            tr[name] = t
+            setattr(tr_c, name, t.data_ptr())
+    check(lib().ilqr_solve_batched(
+        C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(x0), _ptr(us_init), _ptr(_req(delta, torch.float64)),
+        _ptr(_req(k, torch.float64)), _ptr(_req(K, torch.float64)), _ptr(res["xs"]), _ptr(res["us"]),
+        _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),
+        C.byref(tr_c) if tr_c is not None else None, _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
+    res.update(delta=delta, k=k, K=K, trace=tr, workspace=workspace)
+    return res
+
+
+def boxqp_batched(H, g, lower, upper, x0, O):
+    import torch
+    B, m = g.shape
+    dev = g.device
+    x = torch.empty((B, m), dtype=torch.float64, device=dev)
+    Hff = torch.empty((B, m, m), dtype=torch.float64, device=dev)
+    result = torch.empty(B, dtype=torch.int32, device=dev)
+    hd = torch.empty(B, dtype=torch.int32, device=dev)
+    free = torch.empty((B, m), dtype=torch.int32, device=dev)
+    cnt = torch.empty((B, 3), dtype=torch.int32, device=dev)
+    check(lib().ilqr_boxqp_batched(C.c_int64(B), C.c_int32(m), _ptr(_req(H, torch.float64)),
+                                   _ptr(_req(g, torch.float64)), _ptr(_req(lower, torch.float64)),
+                                   _ptr(_req(upper, torch.float64)),
+                                   _ptr(None if x0 is None else _req(x0, torch.float64)), C.byref(O.c), _ptr(x),
+                                   _ptr(result), _ptr(Hff), _ptr(hd), _ptr(free), _ptr(cnt), _stream()))
+    return dict(x=x, result=result, Hff=Hff, hff_dim=hd, free=free, counters=cnt)
+
+
+def plant_step(st, u, gravity=9.8, masscart=1.0, masspole=0.1, length=0.5, tau=0.05):
+    import torch
+    B = st.shape[0]
+    par = _host([gravity, masscart, masspole, length, tau], (5,))
+    out = torch.empty_like(st)
+    check(lib().ilqr_cartpole_plant_step(C.c_int64(B), par.ctypes.data_as(_dp), _ptr(_req(st, torch.float64)),
+                                         _ptr(_req(u.reshape(B), torch.float64)), _ptr(out), _stream()))
+    return out
+
+
+def detmath(a, b):
+    import torch
+    n = a.numel()
+    outs = [torch.empty_like(a) for _ in range(5)]
+    check(lib().ilqr_detmath(C.c_int64(n), _ptr(_req(a, torch.float64)), _ptr(_req(b, torch.float64)),
+                             *[_ptr(o) for o in outs], _stream()))
+    return outs

@@ -322,4 +322,179 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double g, dou
     out.n_backtrack = n_bt;
 }
 
+// ---- backward step ----------------------------------------------------------
+
+struct BwAcc {          // running state of one backward sweep
+    double Vx[NX];
+    double Vxx[NX * NX];
+    double dJ1, dJ2;
+    int qp_iter, qp_backtrack, n_clamped;
+};
+
+enum { BW_OK = 0, BW_NOT_PD = 1, BW_LINALG = 2 };
+
+__device__ __forceinline__ void bw_init(const QRCostP& C, const double (&xT)[NX], BwAcc& S)
+{
+    // V_x, V_xx = terminal l_x, l_xx (ilqr_core.py:120-121)
+    qr_lx(C.QQt, C.xg, xT, S.Vx);
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i)
+        S.Vxx[i] = C.QQt[i];
+    S.dJ1 = 0.0;
+    S.dJ2 = 0.0;
+    S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+}
+
+// One step i of _backward_pass (ilqr_core.py:127-176) with _compute_Q_terms
+// (:179-228) inlined for the cart-pole sparsity pattern and m = 1.
+// Returns BW_OK (k_out, K_out, S updated), BW_NOT_PD (the reference prints,
+// warns and breaks, :137-140) or BW_LINALG (eigvals would raise on a non-finite
+// Q_uu, :291).
+__device__ __forceinline__ int bw_step(const QRCostP& C, const QPOptsP& QO, const CartpoleJac& J,
+                                       double dt, const double (&x)[NX], double u, double mu,
+                                       double lower, double upper, BwAcc& S, double& k_out,
+                                       double (&K_out)[NX], int& qp_result, bool& qp_free)
+{
+    double lx[NX];
+    qr_lx(C.QQ, C.xg, x, lx);
+    double lu = (u - C.ug) * C.RR; // u_diff^T (R + R^T), ilqr_cost.py:586-587
+
+    // column c (>= 2) of f_x is [0, a[0][c-2], a[1][c-2], a[2][c-2], a[3][c-2]]
+    const double(&A)[4][3] = J.a;
+    const double* Vx = S.Vx;
+    const double* Vxx = S.Vxx;
+
+    // Q_x = l_x + f_x^T V_x ; Q_u = l_u + f_u^T V_x      (:206-207)
+    double Qx[NX];
+    Qx[0] = lx[0] + Vx[0];
+    Qx[1] = lx[1] + (dt * Vx[0] + Vx[1]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double acc = A[0][c] * Vx[1];
+        acc = fma(A[1][c], Vx[2], acc);
+        acc = fma(A[2][c], Vx[3], acc);
+        acc = fma(A[3][c], Vx[4], acc);
+        Qx[2 + c] = lx[2 + c] + acc;
+    }
+    double Qu = lu + fma(J.b4, Vx[4], J.b1 * Vx[1]);
+
+    // M1 = f_x^T V_xx ; Q_xx = l_xx + M1 f_x            (:208)
+    double M1[NX * NX];
+#pragma unroll
+    for (int b = 0; b < NX; ++b) {
+        M1[0 * NX + b] = Vxx[0 * NX + b];
+        M1[1 * NX + b] = dt * Vxx[0 * NX + b] + Vxx[1 * NX + b];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = A[0][c] * Vxx[1 * NX + b];
+            acc = fma(A[1][c], Vxx[2 * NX + b], acc);
+            acc = fma(A[2][c], Vxx[3 * NX + b], acc);
+            acc = fma(A[3][c], Vxx[4 * NX + b], acc);
+            M1[(2 + c) * NX + b] = acc;
+        }
+    }
+    double Qxx[NX * NX];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+        Qxx[a * NX + 0] = C.QQ[a * NX + 0] + M1[a * NX + 0];
+        Qxx[a * NX + 1] = C.QQ[a * NX + 1] + (M1[a * NX + 0] * dt + M1[a * NX + 1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = M1[a * NX + 1] * A[0][c];
+            acc = fma(M1[a * NX + 2], A[1][c], acc);
+            acc = fma(M1[a * NX + 3], A[2][c], acc);
+            acc = fma(M1[a * NX + 4], A[3][c], acc);
+            Qxx[a * NX + 2 + c] = C.QQ[a * NX + 2 + c] + acc;
+        }
+    }
+
+    // reg = V_xx + mu I ; M2 = f_u^T reg ; Q_ux = l_ux + M2 f_x ; Q_uu = l_uu + M2 f_u   (:210-212)
+    double M2[NX];
+#pragma unroll
+    for (int b = 0; b < NX; ++b) {
+        double r1 = Vxx[1 * NX + b] + (b == 1 ? mu : 0.0);
+        double r4 = Vxx[4 * NX + b] + (b == 4 ? mu : 0.0);
+        M2[b] = fma(J.b4, r4, J.b1 * r1);
+    }
+    double Qux[NX];
+    Qux[0] = 0.0 + M2[0];
+    Qux[1] = 0.0 + (M2[0] * dt + M2[1]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double acc = M2[1] * A[0][c];
+        acc = fma(M2[2], A[1][c], acc);
+        acc = fma(M2[3], A[2][c], acc);
+        acc = fma(M2[4], A[3][c], acc);
+        Qux[2 + c] = 0.0 + acc;
+    }
+    double Quu = C.RR + fma(M2[4], J.b4, M2[1] * J.b1);
+
+    // np.all(np.linalg.eigvals(Q_uu) > 0), then cholesky   (:137-141)
+    if (!(fabs(Quu) < __builtin_inf()))
+        return BW_LINALG;
+    if (!(Quu > 0.0))
+        return BW_NOT_PD;
+    double L = sqrt(Quu);
+    double rL = 1.0 / L;
+    // k[i] = cho_solve((R_Q_uu, True), Q_u): the (positive-sign) boxQP warm start   (:145)
+    double k0 = (Qu * rL) * rL;
+
+    // boxQP(Q_uu, Q_u, lower - u, upper - u, k[i], ...)     (:152-156)
+    QP1Out qp;
+    boxqp1(QO, Quu, Qu, lower - u, upper - u, k0, qp);
+    double kk = qp.x;
+    S.qp_iter += qp.n_iter;
+    S.qp_backtrack += qp.n_backtrack;
+    S.n_clamped += qp.free_ ? 0 : 1;
+    qp_result = qp.result;
+    qp_free = qp.free_;
+
+    // K[i, free, :] = -cho_solve((H_ff, True), Q_ux[free, :]); clamped rows stay 0   (:157-160)
+    double K[NX];
+#pragma unroll
+    for (int b = 0; b < NX; ++b)
+        K[b] = qp.free_ ? ((Qux[b] * qp.rdiag) * qp.rdiag) * -1 : 0.0;
+
+    // V_x = Q_x + K^T Q_uu k + K^T Q_u + Q_ux^T k                    (:164)
+    // V_xx = Q_xx + K^T Q_uu K + K^T Q_ux + Q_ux^T K, symmetrised    (:167-169)
+    double T1[NX];
+#pragma unroll
+    for (int a = 0; a < NX; ++a)
+        T1[a] = K[a] * Quu;
+    double Vn[NX * NX];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+        S.Vx[a] = ((Qx[a] + T1[a] * kk) + K[a] * Qu) + Qux[a] * kk;
+#pragma unroll
+        for (int b = 0; b < NX; ++b)
+            Vn[a * NX + b] = ((Qxx[a * NX + b] + T1[a] * K[b]) + K[a] * Qux[b]) + Qux[a] * K[b];
+    }
+#pragma unroll
+    for (int a = 0; a < NX; ++a)
+#pragma unroll
+        for (int b = 0; b < NX; ++b)
+            S.Vxx[a * NX + b] = 0.5 * (Vn[a * NX + b] + Vn[b * NX + a]);
+
+    // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)                 (:175-176)
+    S.dJ1 = S.dJ1 + kk * Qu;
+    S.dJ2 = S.dJ2 + (kk * (Quu * kk)) * 0.5;
+
+    k_out = kk;
+#pragma unroll
+    for (int b = 0; b < NX; ++b)
+        K_out[b] = K[b];
+    return BW_OK;
+}
+
+// u_new = u + alpha k + K (x_new - x), ilqr_core.py:104 (never clamped)
+__device__ __forceinline__ double fw_control(const double (&xn)[NX], const double (&xo)[NX], double u,
+                                             double kk, const double (&K)[NX], double alpha)
+{
+    double acc = K[0] * (xn[0] - xo[0]);
+#pragma unroll
+    for (int a = 1; a < NX; ++a)
+        acc = fma(K[a], xn[a] - xo[a], acc);
+    return (u + alpha * kk) + acc;
+}
+
 } // namespace ilqr

@@ -1,0 +1,1070 @@
+// HIP kernels (gfx950) and the C ABI of the batched control-limited iLQR solve.
+// Mapping: one problem per lane, 64 problems per wavefront, every per-problem
+// matrix in registers, trajectories and gains streamed from HBM in batch-minor
+// layout ([row, ld] with the problem index innermost) so that each wave access
+// is one contiguous 512-byte segment.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/ilqr_hip.h"
+#include "ilqr_device.hpp"
+
+using namespace ilqr;
+
+namespace {
+
+constexpr int WAVE = 64;
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? ILQR_OK : ILQR_ERR_HIP; }
+
+struct BoundsP {
+    double lo, hi;
+};
+
+// ---------------------------------------------------------------- helpers
+
+__device__ __forceinline__ void load5(const double* base, int64_t ld, int64_t row0, int64_t b,
+                                      double (&v)[NX])
+{
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+        v[i] = base[(row0 + i) * ld + b];
+}
+
+__device__ __forceinline__ void store5(double* base, int64_t ld, int64_t row0, int64_t b,
+                                       const double (&v)[NX])
+{
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+        base[(row0 + i) * ld + b] = v[i];
+}
+
+// ------------------------------------------------------ layout conversion
+
+// ref [B, R] -> bm [R, ld]: 64x64 tile through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void k_pack(const double* __restrict__ src, double* __restrict__ dst,
+                                              int64_t B, int64_t R, int64_t ld)
+{
+    __shared__ double tile[64][65];
+    int64_t b0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        int64_t b = b0 + j, r = r0 + tx;
+        tile[j][tx] = (b < B && r < R) ? src[b * R + r] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        int64_t r = r0 + j, b = b0 + tx;
+        if (r < R && b < B)
+            dst[r * ld + b] = tile[tx][j];
+    }
+}
+
+// bm [R, ld] -> ref [B, R]; with sel != nullptr problem b reads srcB when sel[b] != 0.
+__global__ __launch_bounds__(256) void k_unpack(const double* __restrict__ srcA,
+                                                const double* __restrict__ srcB,
+                                                const int32_t* __restrict__ sel,
+                                                double* __restrict__ dst, int64_t B, int64_t R,
+                                                int64_t ld)
+{
+    __shared__ double tile[64][65];
+    int64_t b0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)blockIdx.y * 64;
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int64_t bl = b0 + tx;
+    const double* src = srcA;
+    if (sel != nullptr && bl < B && sel[bl] != 0)
+        src = srcB;
+    for (int j = ty; j < 64; j += 4) {
+        int64_t r = r0 + j;
+        tile[j][tx] = (r < R && bl < B) ? src[r * ld + bl] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        int64_t b = b0 + j, r = r0 + tx;
+        if (b < B && r < R)
+            dst[b * R + r] = tile[tx][j];
+    }
+}
+
+// ------------------------------------------------------- rollout and cost
+
+// _dynamics_rollout + _trajectory_cost (ilqr_core.py:69-83, :230-239)
+__global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP C, int T, int64_t B,
+                                                       int64_t ld, const double* __restrict__ x0,
+                                                       const double* __restrict__ us,
+                                                       double* __restrict__ xs, double* __restrict__ Jout)
+{
+    int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B)
+        return;
+    CartpoleC P = cartpole_consts(mp);
+    double x[NX], xn[NX];
+    load5(x0, ld, 0, b, x);
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double u = us[(int64_t)t * ld + b];
+        store5(xs, ld, (int64_t)t * NX, b, x);
+        J = J + qr_l(C, x, u);
+        cartpole_f(P, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            x[i] = xn[i];
+    }
+    store5(xs, ld, (int64_t)T * NX, b, x);
+    Jout[b] = J + qr_l_terminal(C, x);
+}
+
+// ------------------------------------------------- derivative tensor stream
+
+// One thread per (problem, step): f_x, f_u, l_x, l_u, l_xx, l_uu, l_ux as dense
+// batch-minor streams (what _compute_Q_terms asks the model for, ilqr_core.py:189-198).
+__global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP C, int T, int64_t B, int64_t ld,
+                                               const double* __restrict__ xs,
+                                               const double* __restrict__ us, ilqr_deriv_bm_t o)
+{
+    int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int t = blockIdx.y;
+    if (b >= B)
+        return;
+    CartpoleC P = cartpole_consts(mp);
+    double x[NX];
+    load5(xs, ld, (int64_t)t * NX, b, x);
+    if (t == T) { // terminal l_x, l_xx (ilqr_core.py:120-121)
+        double lx[NX];
+        qr_lx(C.QQt, C.xg, x, lx);
+        store5(o.lxT, ld, 0, b, lx);
+        for (int i = 0; i < NX * NX; ++i)
+            o.lxxT[(int64_t)i * ld + b] = C.QQt[i];
+        return;
+    }
+    double u = us[(int64_t)t * ld + b];
+    double th = det_atan2(x[2], x[3]);
+    double sn, cn;
+    det_sincos(th + x[4] * P.dt, sn, cn);
+    CartpoleJac J;
+    cartpole_jac(P, x, u, sn, cn, J);
+    double fx[NX * NX];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i)
+        fx[i] = 0.0;
+    fx[0] = 1.0;
+    fx[1] = P.dt;
+    fx[1 * NX + 1] = 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            fx[(r + 1) * NX + 2 + c] = J.a[r][c];
+    int64_t base = (int64_t)t * NX * NX;
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) {
+        o.fx[(base + i) * ld + b] = fx[i];
+        o.lxx[(base + i) * ld + b] = C.QQ[i];
+    }
+    double fu[NX] = {0.0, J.b1, 0.0, 0.0, J.b4};
+    double lx[NX], zero[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    qr_lx(C.QQ, C.xg, x, lx);
+    store5(o.fu, ld, (int64_t)t * NX, b, fu);
+    store5(o.lx, ld, (int64_t)t * NX, b, lx);
+    store5(o.lux, ld, (int64_t)t * NX, b, zero);
+    o.lu[(int64_t)t * ld + b] = (u - C.ug) * C.RR;
+    o.luu[(int64_t)t * ld + b] = C.RR;
+}
+
+// ------------------------------------------------------------ backward pass
+
+// One backward sweep for problem b.  Writes k [T, ld], K [T*5, ld]; rows the
+// sweep does not reach are zero (np.zeros_like at ilqr_core.py:118-119).
+// TRUST_NEXT: take sin/cos of next_theta from xs[t+1] (valid when xs is a rollout
+// of us through cartpole_f) instead of re-evaluating them.
+template <bool TRUST_NEXT>
+__device__ __forceinline__ int backward_sweep(const CartpoleC& P, const QRCostP& C, const QPOptsP& QO,
+                                              const BoundsP& bd, int T, int64_t ld, int64_t b,
+                                              const double* __restrict__ xs,
+                                              const double* __restrict__ us, double mu,
+                                              double* __restrict__ k, double* __restrict__ K,
+                                              BwAcc& S, int& stopped_at, int32_t* qp_result_bm,
+                                              int32_t* free_bm)
+{
+    double xnext[NX];
+    load5(xs, ld, (int64_t)T * NX, b, xnext);
+    bw_init(C, xnext, S);
+    stopped_at = -1;
+    double x[NX], u;
+    load5(xs, ld, (int64_t)(T - 1) * NX, b, x);
+    u = us[(int64_t)(T - 1) * ld + b];
+    int rc = BW_OK;
+    int i = T - 1;
+    for (; i >= 0; --i) {
+        // prefetch the operands of step i-1 while step i computes
+        double xp[NX], up = 0.0;
+        if (i > 0) {
+            load5(xs, ld, (int64_t)(i - 1) * NX, b, xp);
+            up = us[(int64_t)(i - 1) * ld + b];
+        } else {
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+                xp[a] = 0.0;
+        }
+        double sn, cn;
+        if (TRUST_NEXT) {
+            sn = xnext[2];
+            cn = xnext[3];
+        } else {
+            double th = det_atan2(x[2], x[3]);
+            det_sincos(th + x[4] * P.dt, sn, cn);
+        }
+        CartpoleJac J;
+        cartpole_jac(P, x, u, sn, cn, J);
+        double kk, Kr[NX];
+        int qres;
+        bool qfree;
+        rc = bw_step(C, QO, J, P.dt, x, u, mu, bd.lo, bd.hi, S, kk, Kr, qres, qfree);
+        if (rc != BW_OK)
+            break;
+        k[(int64_t)i * ld + b] = kk;
+        store5(K, ld, (int64_t)i * NX, b, Kr);
+        if (qp_result_bm)
+            qp_result_bm[(int64_t)i * ld + b] = qres;
+        if (free_bm)
+            free_bm[(int64_t)i * ld + b] = qfree ? 1 : 0;
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            xnext[a] = x[a];
+            x[a] = xp[a];
+        }
+        u = up;
+    }
+    if (rc != BW_OK) {
+        if (rc == BW_NOT_PD)
+            stopped_at = i;
+        for (int j = i; j >= 0; --j) { // the steps the reference never reaches keep zeros
+            k[(int64_t)j * ld + b] = 0.0;
+            for (int a = 0; a < NX; ++a)
+                K[((int64_t)j * NX + a) * ld + b] = 0.0;
+            if (qp_result_bm)
+                qp_result_bm[(int64_t)j * ld + b] = -100;
+            if (free_bm)
+                free_bm[(int64_t)j * ld + b] = 0;
+        }
+    }
+    return rc;
+}
+
+__global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP C, QPOptsP QO, BoundsP bd,
+                                                   int T, int64_t B, int64_t ld,
+                                                   const double* __restrict__ xs,
+                                                   const double* __restrict__ us,
+                                                   const double* __restrict__ mu,
+                                                   double* __restrict__ k, double* __restrict__ K,
+                                                   double* __restrict__ dJ, int32_t* __restrict__ info,
+                                                   int32_t* qp_result_bm, int32_t* free_bm)
+{
+    int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B)
+        return;
+    CartpoleC P = cartpole_consts(mp);
+    BwAcc S;
+    int stopped_at;
+    int rc = backward_sweep<false>(P, C, QO, bd, T, ld, b, xs, us, mu[b], k, K, S, stopped_at,
+                                   qp_result_bm, free_bm);
+    dJ[b] = S.dJ1;
+    dJ[ld + b] = S.dJ2;
+    info[b] = stopped_at;
+    info[ld + b] = S.qp_iter;
+    info[2 * ld + b] = S.qp_backtrack;
+    info[3 * ld + b] = S.n_clamped;
+    info[4 * ld + b] = rc;
+}
+
+// ------------------------------------------------------------- forward pass
+
+// _forward_pass + _trajectory_cost for one (problem, alpha)   (ilqr_core.py:85-107, :230-239).
+// xs_new / us_new may be null (cost only).
+__device__ __forceinline__ double forward_rollout(const CartpoleC& P, const QRCostP& C, int T,
+                                                  int64_t ld, int64_t b,
+                                                  const double* __restrict__ xs,
+                                                  const double* __restrict__ us,
+                                                  const double* __restrict__ k,
+                                                  const double* __restrict__ K, double alpha,
+                                                  double* __restrict__ xs_new,
+                                                  double* __restrict__ us_new)
+{
+    double xn[NX], xo[NX], Kr[NX], xt[NX];
+    load5(xs, ld, 0, b, xn);
+    double J = 0.0;
+    // operands of step 0
+    load5(xs, ld, 0, b, xo);
+    load5(K, ld, 0, b, Kr);
+    double u = us[b], kk = k[b];
+    for (int t = 0; t < T; ++t) {
+        // prefetch step t+1
+        double xo_p[NX], Kr_p[NX], u_p = 0.0, kk_p = 0.0;
+        if (t + 1 < T) {
+            load5(xs, ld, (int64_t)(t + 1) * NX, b, xo_p);
+            load5(K, ld, (int64_t)(t + 1) * NX, b, Kr_p);
+            u_p = us[(int64_t)(t + 1) * ld + b];
+            kk_p = k[(int64_t)(t + 1) * ld + b];
+        } else {
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                xo_p[a] = 0.0;
+                Kr_p[a] = 0.0;
+            }
+        }
+        double un = fw_control(xn, xo, u, kk, Kr, alpha);
+        J = J + qr_l(C, xn, un);
+        if (xs_new) {
+            store5(xs_new, ld, (int64_t)t * NX, b, xn);
+            us_new[(int64_t)t * ld + b] = un;
+        }
+        cartpole_f(P, xn, un, xt);
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            xn[a] = xt[a];
+            xo[a] = xo_p[a];
+            Kr[a] = Kr_p[a];
+        }
+        u = u_p;
+        kk = kk_p;
+    }
+    if (xs_new)
+        store5(xs_new, ld, (int64_t)T * NX, b, xn);
+    return J + qr_l_terminal(C, xn);
+}
+
+struct AlphasP {
+    double a[32];
+};
+
+// Lanes = problems, blockIdx.y = alpha: every (problem, alpha) pair in parallel.
+__global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP C, AlphasP al, int T,
+                                                     int64_t B, int64_t ld,
+                                                     const double* __restrict__ xs,
+                                                     const double* __restrict__ us,
+                                                     const double* __restrict__ k,
+                                                     const double* __restrict__ K,
+                                                     double* __restrict__ Jnew,
+                                                     double* __restrict__ xs_new,
+                                                     double* __restrict__ us_new)
+{
+    int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    int ai = blockIdx.y;
+    if (b >= B)
+        return;
+    CartpoleC P = cartpole_consts(mp);
+    double* xo = xs_new ? xs_new + (int64_t)ai * (T + 1) * NX * ld : nullptr;
+    double* uo = us_new ? us_new + (int64_t)ai * T * ld : nullptr;
+    Jnew[(int64_t)ai * ld + b] = forward_rollout(P, C, T, ld, b, xs, us, k, K, al.a[ai], xo, uo);
+}
+
+// ------------------------------------------------------------- whole solve
+
+struct SolveBuffers {       // batch-minor workspace, two copies of everything that is swapped
+    double* xs[2];          // [(T+1)*5, ld]
+    double* us[2];          // [T, ld]
+    double* k[2];           // [T, ld]
+    double* K[2];           // [T*5, ld]
+    int32_t* sel_traj;      // [B] which copy holds the final trajectory
+    int32_t* sel_gain;      // [B] which copy holds the final gains
+};
+
+// iLQR.update_u (ilqr_core.py:241-399): every lane runs its own problem to
+// termination; no host involvement per iteration.
+__global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP C, SolveOptsP O, BoundsP bd, int T,
+                                                int64_t B, int64_t ld, SolveBuffers W,
+                                                double* __restrict__ delta_io,
+                                                double* __restrict__ J_out, double* __restrict__ mu_out,
+                                                int32_t* __restrict__ iters_out,
+                                                int32_t* __restrict__ status_out, ilqr_trace tr)
+{
+    int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B)
+        return;
+    CartpoleC P = cartpole_consts(mp);
+    int cur = 0;  // trajectory copy in use
+    int gcur = 0; // gain copy in use (holds the solver's k_/K_ on entry)
+    double mu = 1.0; // reset per call (:264); delta_ persists (:62)
+    double delta = delta_io[b];
+
+    // initial rollout and cost (:269-271); us_init is in W.us[0], x0 in rows 0..4 of W.xs[0]
+    double J;
+    {
+        double x[NX], xn[NX];
+        load5(W.xs[0], ld, 0, b, x);
+        J = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double u = W.us[0][(int64_t)t * ld + b];
+            if (t > 0)
+                store5(W.xs[0], ld, (int64_t)t * NX, b, x);
+            J = J + qr_l(C, x, u);
+            cartpole_f(P, x, u, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                x[i] = xn[i];
+        }
+        store5(W.xs[0], ld, (int64_t)T * NX, b, x);
+        J = J + qr_l_terminal(C, x);
+    }
+
+    double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
+    int converged = 0, status = ILQR_RAN_OUT;
+    int it = 0;
+    for (it = 0; it < O.max_iter; ++it) {
+        const double* xs = W.xs[cur];
+        const double* us = W.us[cur];
+        // ---- backward pass, with the LinAlgError retry loop (:287-299)
+        BwAcc S;
+        int stopped_at = -1;
+        S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+        bool done = false;
+        while (!done) {
+            int gnew = gcur ^ 1;
+            int rc = backward_sweep<true>(P, C, O.qp, bd, T, ld, b, xs, us, mu, W.k[gnew], W.K[gnew], S,
+                                          stopped_at, nullptr, nullptr);
+            if (rc != BW_LINALG) {
+                gcur = gnew;
+                dJ1 = S.dJ1;
+                dJ2 = S.dJ2;
+                done = true;
+            } else {
+                delta = fmax(delta, 1.0) * O.delta0;
+                mu = fmax(O.mu_min, mu * delta);
+                if (O.mu_max != 0.0 && mu >= O.mu_max)
+                    break;
+            }
+        }
+        // ---- serial first-hit line search (:301-313)
+        int accepted = 0;
+        int j = 0;
+        double Jnew = 0.0;
+        int nxt = cur ^ 1;
+        for (j = 0; j < O.n_alpha; ++j) {
+            double alpha = O.alphas[j];
+            Jnew = forward_rollout(P, C, T, ld, b, xs, us, W.k[gcur], W.K[gcur], alpha, W.xs[nxt],
+                                   W.us[nxt]);
+            double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+            if (expected <= 0.0) {
+                break;
+            } else if ((J - Jnew) / expected > O.scale) {
+                actual = J - Jnew;
+                accepted = 1;
+                break;
+            }
+        }
+        // ---- regularisation schedule and termination (:315-339)
+        bool stop = false;
+        if (accepted) {
+            delta = fmin(1.0, delta) / O.delta0;
+            mu = mu * delta;
+            if (mu <= O.mu_min)
+                mu = 0.0;
+            J = Jnew;
+            cur = nxt;
+            if (actual < O.tol)
+                converged = 1;
+        } else {
+            delta = fmax(delta, 1.0) * O.delta0;
+            mu = fmax(O.mu_min, mu * delta);
+            if (O.mu_max != 0.0 && mu >= O.mu_max) {
+                status = ILQR_MU_MAX;
+                stop = true;
+            }
+        }
+        int64_t to = (int64_t)it * B + b;
+        if (tr.J) tr.J[to] = J;
+        if (tr.accepted) tr.accepted[to] = accepted;
+        if (tr.alpha_idx) tr.alpha_idx[to] = j;
+        if (tr.mu) tr.mu[to] = mu;
+        if (tr.delta) tr.delta[to] = delta;
+        if (tr.qp_iter) tr.qp_iter[to] = S.qp_iter;
+        if (tr.qp_backtrack) tr.qp_backtrack[to] = S.qp_backtrack;
+        if (tr.n_clamped) tr.n_clamped[to] = S.n_clamped;
+        if (tr.stopped_at) tr.stopped_at[to] = stopped_at;
+        if (stop) {
+            ++it;
+            break;
+        }
+        if (converged) {
+            status = ILQR_CONVERGED;
+            ++it;
+            break;
+        }
+    }
+    delta_io[b] = delta;
+    J_out[b] = J;
+    mu_out[b] = mu;
+    iters_out[b] = it;
+    status_out[b] = status;
+    W.sel_traj[b] = cur;
+    W.sel_gain[b] = gcur;
+}
+
+// ------------------------------------------------------- stand-alone boxQP
+
+constexpr int QM = 8; // largest boxQP dimension of the stand-alone kernel
+
+// (v^T M) . v, ilqr_boxQP.py:62
+__device__ double qpg_quad(int m, const double* v, const double* M)
+{
+    double tot = 0.0;
+    for (int j = 0; j < m; ++j) {
+        double acc = v[0] * M[j];
+        for (int i = 1; i < m; ++i)
+            acc = fma(v[i], M[i * m + j], acc);
+        tot = (j == 0) ? acc * v[0] : fma(acc, v[j], tot);
+    }
+    return tot;
+}
+
+__device__ double qpg_value(int m, const double* H, const double* g, const double* x)
+{
+    double xg = x[0] * g[0];
+    for (int i = 1; i < m; ++i)
+        xg = fma(x[i], g[i], xg);
+    return xg + 0.5 * qpg_quad(m, x, H);
+}
+
+// Lower Cholesky of the leading d x d block (row stride ld_); 0 ok, 1 = pivot not > 0.
+__device__ int qpg_chol(int d, const double* A, int lda, double* L, int ldl)
+{
+    for (int j = 0; j < d; ++j) {
+        double s = A[j * lda + j];
+        for (int k = 0; k < j; ++k)
+            s = fma(-L[j * ldl + k], L[j * ldl + k], s);
+        if (!(s > 0.0))
+            return 1;
+        double d_jj = sqrt(s);
+        double r_jj = 1.0 / d_jj;
+        L[j * ldl + j] = d_jj;
+        for (int i = j + 1; i < d; ++i) {
+            double t = A[i * lda + j];
+            for (int k = 0; k < j; ++k)
+                t = fma(-L[i * ldl + k], L[j * ldl + k], t);
+            L[i * ldl + j] = t * r_jj;
+        }
+    }
+    return 0;
+}
+
+// Solve (L L^T) x = b in place, multiplying by reciprocal diagonals.
+__device__ void qpg_solve(int d, const double* L, int ldl, double* b)
+{
+    for (int i = 0; i < d; ++i) {
+        double s = b[i];
+        for (int j = 0; j < i; ++j)
+            s = fma(-L[i * ldl + j], b[j], s);
+        b[i] = s * (1.0 / L[i * ldl + i]);
+    }
+    for (int i = d - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int j = i + 1; j < d; ++j)
+            s = fma(-L[j * ldl + i], b[j], s);
+        b[i] = s * (1.0 / L[i * ldl + i]);
+    }
+}
+
+// boxQP (ilqr_boxQP.py:9-186) for m <= 8, one QP per lane, ref layout.
+__global__ __launch_bounds__(WAVE) void k_boxqp(QPOptsP O, int64_t B, int m, const double* __restrict__ Hg,
+                                                const double* __restrict__ gg,
+                                                const double* __restrict__ lowerg,
+                                                const double* __restrict__ upperg,
+                                                const double* __restrict__ x0g, double* __restrict__ xg_out,
+                                                int32_t* __restrict__ result_out, double* __restrict__ Hff_out,
+                                                int32_t* __restrict__ hd_out, int32_t* __restrict__ free_out,
+                                                int32_t* __restrict__ cnt_out)
+{
+    int64_t q = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (q >= B)
+        return;
+    double H[QM * QM], g[QM], lower[QM], upper[QM], x[QM], Hff[QM * QM];
+    double grad[QM], search[QM], xc[QM], rhs[QM], sub[QM * QM], Lfull[QM * QM];
+    int clamped[QM], freev[QM], oldclamped[QM], fidx[QM], cidx[QM];
+    for (int i = 0; i < m * m; ++i) {
+        H[i] = Hg[q * m * m + i];
+        Hff[i] = 1.0; // H_ff = np.ones((n, n)), :36
+    }
+    bool h_finite = true;
+    for (int i = 0; i < m * m; ++i)
+        h_finite = h_finite && (fabs(H[i]) < __builtin_inf());
+    for (int i = 0; i < m; ++i) {
+        g[i] = gg[q * m + i];
+        lower[i] = lowerg[q * m + i];
+        upper[i] = upperg[q * m + i];
+        clamped[i] = 0;
+        freev[i] = 0;
+        x[i] = x0g ? clamp1(lower[i], upper[i], x0g[q * m + i]) : (lower[i] + upper[i]) / 2;
+    }
+    double value = qpg_value(m, H, g, x), oldvalue = 0.0;
+    int result = -1, hd = m, n_iter = 0, n_factor = 0, n_bt = 0;
+    bool h_pd = h_finite && qpg_chol(m, H, m, Lfull, m) == 0;
+    bool linalg = false;
+
+    for (int iter = 0; iter < O.max_iter; ++iter) {
+        if (result != -1)
+            break;
+        if (iter > 1 && (oldvalue - value) < O.min_rel * fabs(oldvalue) && (oldvalue - value) > 0.0) {
+            result = 4;
+            break;
+        }
+        oldvalue = value;
+        for (int i = 0; i < m; ++i) {
+            double acc = H[i * m] * x[0];
+            for (int j = 1; j < m; ++j)
+                acc = fma(H[i * m + j], x[j], acc);
+            grad[i] = g[i] + acc;
+        }
+        int nclamped = 0;
+        for (int i = 0; i < m; ++i) {
+            oldclamped[i] = clamped[i];
+            clamped[i] = ((x[i] == lower[i]) && (grad[i] > 0.0)) || ((x[i] == upper[i]) && (grad[i] < 0.0));
+            freev[i] = !clamped[i];
+            nclamped += clamped[i];
+        }
+        if (nclamped == m) {
+            result = 6;
+            break;
+        }
+        if (!h_finite) { // eigvals raises LinAlgError
+            linalg = true;
+            break;
+        }
+        if (!h_pd) {
+            result = -1;
+            break;
+        }
+        bool factorize = iter == 1;
+        for (int i = 0; i < m; ++i)
+            factorize = factorize || (oldclamped[i] != clamped[i]);
+        int nf = 0, nc = 0;
+        for (int i = 0; i < m; ++i) {
+            if (freev[i])
+                fidx[nf++] = i;
+            else
+                cidx[nc++] = i;
+        }
+        if (factorize) {
+            for (int a = 0; a < nf; ++a)
+                for (int b = 0; b < nf; ++b)
+                    sub[a * m + b] = H[fidx[a] * m + fidx[b]];
+            if (qpg_chol(nf, sub, m, Hff, m) != 0) {
+                linalg = true;
+                break;
+            }
+            hd = nf;
+            ++n_factor;
+        }
+        double ss = 0.0;
+        for (int a = 0; a < nf; ++a)
+            ss = (a == 0) ? grad[fidx[0]] * grad[fidx[0]] : fma(grad[fidx[a]], grad[fidx[a]], ss);
+        double gnorm = nf == 1 ? fabs(grad[fidx[0]]) : sqrt(ss);
+        if (gnorm < O.min_grad) {
+            result = 5;
+            break;
+        }
+        ++n_iter;
+        for (int a = 0; a < nf; ++a) {
+            double acc = 0.0;
+            for (int b = 0; b < nc; ++b)
+                acc = (b == 0) ? H[fidx[a] * m + cidx[0]] * x[cidx[0]]
+                               : fma(H[fidx[a] * m + cidx[b]], x[cidx[b]], acc);
+            rhs[a] = g[fidx[a]] + acc;
+        }
+        qpg_solve(nf, Hff, m, rhs);
+        for (int i = 0; i < m; ++i)
+            search[i] = 0.0;
+        for (int a = 0; a < nf; ++a)
+            search[fidx[a]] = rhs[a] * -1 - x[fidx[a]];
+
+        double step = 1.0;
+        for (int i = 0; i < m; ++i)
+            xc[i] = clamp1(lower[i], upper[i], x[i] + step * search[i]);
+        double sdotg = (xc[0] - x[0]) * grad[0];
+        for (int i = 1; i < m; ++i)
+            sdotg = sdotg + (xc[i] - x[i]) * grad[i];
+        double vc = qpg_value(m, H, g, xc);
+        while ((vc - oldvalue) / (sdotg + 1e-10) < O.armijo) {
+            step = step * O.step_dec;
+            ++n_bt;
+            for (int i = 0; i < m; ++i)
+                xc[i] = clamp1(lower[i], upper[i], x[i] + step * search[i]);
+            vc = qpg_value(m, H, g, xc);
+            sdotg = (xc[0] - x[0]) * grad[0];
+            for (int i = 1; i < m; ++i)
+                sdotg = sdotg + (xc[i] - x[i]) * grad[i];
+            if (step < O.min_step) {
+                result = 2;
+                break;
+            }
+        }
+        for (int i = 0; i < m; ++i)
+            x[i] = xc[i];
+        value = vc;
+    }
+    for (int i = 0; i < m; ++i) {
+        xg_out[q * m + i] = x[i];
+        free_out[q * m + i] = freev[i];
+    }
+    for (int i = 0; i < m * m; ++i)
+        Hff_out[q * m * m + i] = Hff[i];
+    result_out[q] = linalg ? -99 : result; // -99: the reference would raise LinAlgError
+    hd_out[q] = hd;
+    cnt_out[q * 3 + 0] = n_iter;
+    cnt_out[q * 3 + 1] = n_factor;
+    cnt_out[q * 3 + 2] = n_bt;
+}
+
+// -------------------------------------------------------------- plant step
+
+// CartPoleContinuousEnv._state_eq, ilqr/cartpole_gym.py:60-72
+struct PlantP {
+    double g, mc, mp, len, tau;
+};
+
+__global__ __launch_bounds__(256) void k_plant_step(PlantP p, int64_t B, const double* __restrict__ st,
+                                                    const double* __restrict__ u, double* __restrict__ out)
+{
+    int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B)
+        return;
+    double M = p.mp + p.mc, pml = p.mp * p.len;
+    double x = st[b * 4 + 0], xd = st[b * 4 + 1], th = st[b * 4 + 2], thd = st[b * 4 + 3];
+    double force = u[b];
+    double sn, cs;
+    det_sincos(th, sn, cs);
+    double temp = (force + pml * thd * thd * sn) / M;
+    double thacc = (p.g * sn - cs * temp) / (p.len * (4.0 / 3.0 - p.mp * cs * cs / M));
+    double xacc = temp - pml * thacc * cs / M;
+    out[b * 4 + 0] = x + p.tau * xd;
+    out[b * 4 + 1] = xd + p.tau * xacc;
+    out[b * 4 + 2] = th + p.tau * thd;
+    out[b * 4 + 3] = thd + p.tau * thacc;
+}
+
+__global__ __launch_bounds__(256) void k_detmath(int64_t n, const double* a, const double* bb, double* s,
+                                                 double* c, double* t, double* sq, double* dv)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    double sn, cs;
+    det_sincos(a[i], sn, cs);
+    s[i] = sn;
+    c[i] = cs;
+    t[i] = det_atan2(a[i], bb[i]);
+    sq[i] = sqrt(fabs(a[i]));
+    dv[i] = a[i] / bb[i];
+}
+
+// --------------------------------------------------- host-side conversions
+
+int check_model(const ilqr_model* m)
+{
+    if (!m)
+        return ILQR_ERR_ARG;
+    if (m->model != ILQR_MODEL_CARTPOLE || m->n != 5 || m->m != 1 || m->cost_kind != ILQR_COST_QR ||
+        m->control_limit != 1)
+        return ILQR_ERR_UNSUPPORTED;
+    if (m->T < 1 || !m->Q || !m->R || !m->lower || !m->upper)
+        return ILQR_ERR_ARG;
+    return ILQR_OK;
+}
+
+void fill_model(const ilqr_model* m, CartpoleP& mp, QRCostP& C, BoundsP& bd)
+{
+    mp.dt = m->dt;
+    mp.mc = m->mc;
+    mp.mp = m->mp;
+    mp.l = m->l;
+    mp.g = m->g;
+    const double* Qt = m->Q_terminal ? m->Q_terminal : m->Q; // QRCost default, ilqr_cost.py:504-505
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) {
+            C.Q[a * 5 + b] = m->Q[a * 5 + b];
+            C.Qt[a * 5 + b] = Qt[a * 5 + b];
+            C.QQ[a * 5 + b] = m->Q[a * 5 + b] + m->Q[b * 5 + a];
+            C.QQt[a * 5 + b] = Qt[a * 5 + b] + Qt[b * 5 + a];
+        }
+    C.R = m->R[0];
+    C.RR = m->R[0] + m->R[0];
+    for (int a = 0; a < 5; ++a)
+        C.xg[a] = m->x_goal ? m->x_goal[a] : 0.0;
+    C.ug = m->u_goal ? m->u_goal[0] : 0.0;
+    bd.lo = m->lower[0];
+    bd.hi = m->upper[0];
+}
+
+int fill_qp(const ilqr_opts* o, QPOptsP& q)
+{
+    if (!o || o->qp_max_iter < 0 || !(o->qp_step_dec > 0.0) || !(o->qp_step_dec < 1.0) ||
+        !(o->qp_min_step > 0.0))
+        return ILQR_ERR_ARG;
+    q.max_iter = o->qp_max_iter;
+    q.min_grad = o->qp_min_grad;
+    q.min_rel = o->qp_min_rel_improve;
+    q.step_dec = o->qp_step_dec;
+    q.min_step = o->qp_min_step;
+    q.armijo = o->qp_armijo;
+    // number of `step *= stepDec` after which step < minStep (ilqr_boxQP.py:151-159),
+    // with the same rounded multiplications the loop performs
+    volatile double step = 1.0;
+    int n = 0;
+    do {
+        step = step * o->qp_step_dec;
+        ++n;
+    } while (!(step < o->qp_min_step) && n < 1000000);
+    q.n_exhaust = n;
+    return ILQR_OK;
+}
+
+int fill_opts(const ilqr_opts* o, SolveOptsP& s)
+{
+    if (!o || !o->alphas || o->n_alpha < 0 || o->n_alpha > 32 || o->max_iter < 0)
+        return ILQR_ERR_ARG;
+    s.max_iter = o->max_iter;
+    s.n_alpha = o->n_alpha;
+    s.tol = o->tol;
+    s.scale = o->scale;
+    s.mu_min = o->mu_min;
+    s.mu_max = o->mu_max;
+    s.delta0 = o->delta0;
+    for (int i = 0; i < 32; ++i)
+        s.alphas[i] = i < o->n_alpha ? o->alphas[i] : 0.0;
+    return fill_qp(o, s.qp);
+}
+
+inline dim3 tile_grid(int64_t B, int64_t R) { return dim3((unsigned)((B + 63) / 64), (unsigned)((R + 63) / 64)); }
+
+} // namespace
+
+// ==================================================================== C ABI
+
+extern "C" {
+
+int ilqr_version(void) { return 100; }
+
+const char* ilqr_status_string(int s)
+{
+    switch (s) {
+    case ILQR_OK: return "ok";
+    case ILQR_ERR_ARG: return "invalid argument";
+    case ILQR_ERR_UNSUPPORTED: return "model, dimension or option not supported";
+    case ILQR_ERR_HIP: return "HIP runtime error";
+    case ILQR_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown status";
+    }
+}
+
+int64_t ilqr_bm_ld(int64_t B) { return (B + 63) / 64 * 64; }
+
+int ilqr_pack_bm(const double* src, double* dst, int64_t B, int64_t R, int64_t ld, void* stream)
+{
+    if (!src || !dst || B < 1 || R < 1 || ld < B)
+        return ILQR_ERR_ARG;
+    hipLaunchKernelGGL(k_pack, tile_grid(B, R), dim3(256), 0, as_stream(stream), src, dst, B, R, ld);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_unpack_bm(const double* src, double* dst, int64_t B, int64_t R, int64_t ld, void* stream)
+{
+    if (!src || !dst || B < 1 || R < 1 || ld < B)
+        return ILQR_ERR_ARG;
+    hipLaunchKernelGGL(k_unpack, tile_grid(B, R), dim3(256), 0, as_stream(stream), src, src,
+                       (const int32_t*)nullptr, dst, B, R, ld);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_rollout_cost_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* x0,
+                         const double* us, double* xs, double* J, void* stream)
+{
+    int rc = check_model(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (!x0 || !us || !xs || !J || B < 1 || ld < B)
+        return ILQR_ERR_ARG;
+    CartpoleP mp;
+    QRCostP C;
+    BoundsP bd;
+    fill_model(model, mp, C, bd);
+    hipLaunchKernelGGL(k_rollout_cost, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
+                       as_stream(stream), mp, C, model->T, B, ld, x0, us, xs, J);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_deriv_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* xs, const double* us,
+                  const ilqr_deriv_bm_t* out, void* stream)
+{
+    int rc = check_model(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (!xs || !us || !out || B < 1 || ld < B || !out->fx || !out->fu || !out->lx || !out->lu ||
+        !out->lxx || !out->luu || !out->lux || !out->lxT || !out->lxxT)
+        return ILQR_ERR_ARG;
+    CartpoleP mp;
+    QRCostP C;
+    BoundsP bd;
+    fill_model(model, mp, C, bd);
+    hipLaunchKernelGGL(k_deriv, dim3((unsigned)((B + 255) / 256), (unsigned)(model->T + 1)), dim3(256), 0,
+                       as_stream(stream), mp, C, model->T, B, ld, xs, us, *out);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_backward_bm(const ilqr_model* model, const ilqr_opts* opts, int64_t B, int64_t ld,
+                     const double* xs, const double* us, const double* mu,
+                     const ilqr_deriv_bm_t* deriv, double* k, double* K, double* dJ, int32_t* info,
+                     int32_t* qp_result_bm, int32_t* free_bm, void* stream)
+{
+    int rc = check_model(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (deriv != nullptr)
+        return ILQR_ERR_UNSUPPORTED; // the streamed-tensor variant is not built yet
+    if (!xs || !us || !mu || !k || !K || !dJ || !info || B < 1 || ld < B)
+        return ILQR_ERR_ARG;
+    CartpoleP mp;
+    QRCostP C;
+    BoundsP bd;
+    QPOptsP q;
+    fill_model(model, mp, C, bd);
+    rc = fill_qp(opts, q);
+    if (rc != ILQR_OK)
+        return rc;
+    hipLaunchKernelGGL(k_backward, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
+                       as_stream(stream), mp, C, q, bd, model->T, B, ld, xs, us, mu, k, K, dJ, info,
+                       qp_result_bm, free_bm);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_forward_ls_bm(const ilqr_model* model, int64_t B, int64_t ld, int32_t n_alpha,
+                       const double* alphas, const double* xs, const double* us, const double* k,
+                       const double* K, double* J_new, double* xs_new, double* us_new, void* stream)
+{
+    int rc = check_model(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (!alphas || n_alpha < 1 || n_alpha > 32 || !xs || !us || !k || !K || !J_new || B < 1 || ld < B ||
+        ((xs_new == nullptr) != (us_new == nullptr)))
+        return ILQR_ERR_ARG;
+    CartpoleP mp;
+    QRCostP C;
+    BoundsP bd;
+    fill_model(model, mp, C, bd);
+    AlphasP al;
+    for (int i = 0; i < 32; ++i)
+        al.a[i] = i < n_alpha ? alphas[i] : 0.0;
+    hipLaunchKernelGGL(k_forward_ls, dim3((unsigned)((B + WAVE - 1) / WAVE), (unsigned)n_alpha), dim3(WAVE),
+                       0, as_stream(stream), mp, C, al, model->T, B, ld, xs, us, k, K, J_new, xs_new,
+                       us_new);
+    return hip_status(hipGetLastError());
+}
+
+size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B)
+{
+    if (check_model(model) != ILQR_OK || B < 1)
+        return 0;
+    int64_t ld = ilqr_bm_ld(B), T = model->T;
+    int64_t rows = 2 * ((T + 1) * 5 + T + T + T * 5);
+    return (size_t)rows * ld * sizeof(double) + 2 * (size_t)ld * sizeof(int32_t);
+}
+
+int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                       const double* us_init, double* delta, double* k, double* K, double* xs,
+                       double* us, double* J, double* mu, int32_t* iters, int32_t* status,
+                       const ilqr_trace* trace, void* workspace, size_t workspace_bytes, void* stream)
+{
+    int rc = check_model(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (!x0 || !us_init || !delta || !k || !K || !xs || !us || !J || !mu || !iters || !status ||
+        !workspace || B < 1)
+        return ILQR_ERR_ARG;
+    if (workspace_bytes < ilqr_solve_workspace_bytes(model, B))
+        return ILQR_ERR_WORKSPACE;
+    CartpoleP mp;
+    QRCostP C;
+    BoundsP bd;
+    SolveOptsP O;
+    fill_model(model, mp, C, bd);
+    rc = fill_opts(opts, O);
+    if (rc != ILQR_OK)
+        return rc;
+    hipStream_t st = as_stream(stream);
+    int64_t ld = ilqr_bm_ld(B), T = model->T;
+    SolveBuffers W;
+    double* p = static_cast<double*>(workspace);
+    for (int c = 0; c < 2; ++c) {
+        W.xs[c] = p; p += (T + 1) * 5 * ld;
+        W.us[c] = p; p += T * ld;
+        W.k[c] = p;  p += T * ld;
+        W.K[c] = p;  p += T * 5 * ld;
+    }
+    W.sel_traj = reinterpret_cast<int32_t*>(p);
+    W.sel_gain = W.sel_traj + ld;
+
+    hipLaunchKernelGGL(k_pack, tile_grid(B, 5), dim3(256), 0, st, x0, W.xs[0], B, (int64_t)5, ld);
+    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, us_init, W.us[0], B, T, ld);
+    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, (const double*)k, W.k[0], B, T, ld);
+    hipLaunchKernelGGL(k_pack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)K, W.K[0], B, T * 5, ld);
+    ilqr_trace tr;
+    if (trace)
+        tr = *trace;
+    else
+        std::memset(&tr, 0, sizeof(tr));
+    hipLaunchKernelGGL(k_solve, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, mp, C, O, bd,
+                       (int)T, B, ld, W, delta, J, mu, iters, status, tr);
+    hipLaunchKernelGGL(k_unpack, tile_grid(B, (T + 1) * 5), dim3(256), 0, st, (const double*)W.xs[0],
+                       (const double*)W.xs[1], (const int32_t*)W.sel_traj, xs, B, (T + 1) * 5, ld);
+    hipLaunchKernelGGL(k_unpack, tile_grid(B, T), dim3(256), 0, st, (const double*)W.us[0],
+                       (const double*)W.us[1], (const int32_t*)W.sel_traj, us, B, T, ld);
+    hipLaunchKernelGGL(k_unpack, tile_grid(B, T), dim3(256), 0, st, (const double*)W.k[0],
+                       (const double*)W.k[1], (const int32_t*)W.sel_gain, k, B, T, ld);
+    hipLaunchKernelGGL(k_unpack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)W.K[0],
+                       (const double*)W.K[1], (const int32_t*)W.sel_gain, K, B, T * 5, ld);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, const double* lower,
+                       const double* upper, const double* x0, const ilqr_opts* opts, double* x,
+                       int32_t* result, double* Hff, int32_t* hff_dim, int32_t* free_mask,
+                       int32_t* counters, void* stream)
+{
+    if (!H || !g || !lower || !upper || !x || !result || !Hff || !hff_dim || !free_mask || !counters || B < 1)
+        return ILQR_ERR_ARG;
+    if (m < 1 || m > QM)
+        return ILQR_ERR_UNSUPPORTED;
+    QPOptsP q;
+    int rc = fill_qp(opts, q);
+    if (rc != ILQR_OK)
+        return rc;
+    hipLaunchKernelGGL(k_boxqp, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, as_stream(stream), q,
+                       B, (int)m, H, g, lower, upper, x0, x, result, Hff, hff_dim, free_mask, counters);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_cartpole_plant_step(int64_t B, const double* par, const double* st, const double* u, double* out,
+                             void* stream)
+{
+    if (!par || !st || !u || !out || B < 1)
+        return ILQR_ERR_ARG;
+    PlantP p{par[0], par[1], par[2], par[3], par[4]};
+    hipLaunchKernelGGL(k_plant_step, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, as_stream(stream), p,
+                       B, st, u, out);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_detmath(int64_t n, const double* a, const double* b, double* s, double* c, double* t, double* sq,
+                 double* dv, void* stream)
+{
+    if (!a || !b || !s || !c || !t || !sq || !dv || n < 1)
+        return ILQR_ERR_ARG;
+    hipLaunchKernelGGL(k_detmath, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), n, a,
+                       b, s, c, t, sq, dv);
+    return hip_status(hipGetLastError());
+}
+
+} // extern "C"

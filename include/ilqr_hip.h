@@ -121,7 +121,7 @@ int ilqr_deriv_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* 
  *   streams written by ilqr_deriv_bm.
  *   -> k_bm [T*m, ld], K_bm [T*m*n, ld] (zero where the sweep did not reach),
  *      dJ [2, ld] (Delta_J1, Delta_J2),
- *      info [4, ld] int32: stopped_at, qp_iter, qp_backtrack, n_clamped,
+ *      info [5, ld] int32: stopped_at, qp_iter, qp_backtrack, n_clamped, rc (0 ok, 1 not PD, 2 non-finite Q_uu),
  *      qp_result_bm [T, ld] (boxQP result code per step, -100 = not reached; may be NULL),
  *      free_bm [T*m, ld] (boxQP free mask per step; may be NULL). */
 int ilqr_backward_bm(const ilqr_model* model, const ilqr_opts* opts, int64_t B, int64_t ld,
@@ -144,7 +144,9 @@ int ilqr_forward_ls_bm(const ilqr_model* model, int64_t B, int64_t ld, int32_t n
  *   -> x [B,m], result [B] (codes of :173-180), Hff [B,m,m] (free-subspace Cholesky
  *      factor in the leading hff_dim x hff_dim block, row stride m; all ones if no
  *      factorisation happened, :36), hff_dim [B], free_mask [B,m],
- *      counters [B,3] = search steps, factorisations, Armijo reductions. */
+ *      counters [B,3] = search steps, factorisations, Armijo reductions.
+ *   result = -99 marks a QP on which the reference would raise LinAlgError
+ *   (non-finite H, or a free sub-block that is not positive definite). */
 int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, const double* lower,
                        const double* upper, const double* x0, const ilqr_opts* opts, double* x,
                        int32_t* result, double* Hff, int32_t* hff_dim, int32_t* free_mask,

@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bar: every floating-point output equal to the oracle's (deterministic math mode)
+as VALUES, compared with ==, i.e. bit-exact except that -0.0 == +0.0; every
+integer output (iteration counts, boxQP result codes, active sets, line-search
+indices) identical.  The fixtures recorded from the reference's own solver are
+matched to 1e-9 relative on costs with identical discrete decisions.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as co  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ilqr_amd import _hip
+    _hip.lib()
+    return _hip
+
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def hip_model(hip, Mo):
+    p = Mo.params
+    return hip.Model(Mo.T, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=p["dt"], mc=p["mc"],
+                     mp=p["mp"], l=p["l"], g=p["g"])
+
+
+def eq(a, b):
+    """Value equality incl. NaN positions."""
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_device_math_bit_exact(hip):
+    r = np.random.RandomState(0)
+    a = np.concatenate([r.uniform(-10, 10, 300000), r.uniform(-1e5, 1e5, 100000), r.uniform(-4, 4, 100000),
+                        r.uniform(-1e-3, 1e-3, 20000), 10.0 ** r.uniform(-300, 300, 50000),
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 2.0 ** 30, 2.0 ** 30 + 1, 1e300]])
+    b = np.concatenate([r.uniform(-10, 10, a.size - 8), [0.0, 1.0, np.inf, -np.inf, 1.0, np.nan, -0.0, 1e-300]])
+    s, c, t, sq, dv = [o.cpu().numpy() for o in hip.detmath(dev(a), dev(b))]
+    so, cco, to = co.detmath(a, b)
+    assert eq(s, so) and eq(c, cco) and eq(t, to)
+    assert np.array_equal(np.signbit(t), np.signbit(to))
+    # IEEE sqrt and divide on the device are correctly rounded (the oracle relies on it)
+    with np.errstate(all="ignore"):
+        assert eq(sq, np.sqrt(np.abs(a)))
+        assert eq(dv, a / b)
+
+
+@pytest.mark.parametrize("B,T", [(1, 100), (300, 100), (64, 15)])
+def test_rollout_cost_bit_exact(hip, B, T):
+    Mo = co.cartpole_model(T=T)
+    x0, us = co.cartpole_batch(B, T=T, seed_x=3, seed_u=4)
+    us *= 4.0
+    xs_o, J_o = co.rollout_cost(Mo, x0, us)
+    M = hip_model(hip, Mo)
+    xs_bm, J = hip.rollout_cost_bm(M, B, hip.pack_bm(dev(x0)), hip.pack_bm(dev(us)))
+    xs = hip.unpack_bm(xs_bm, B, (T + 1, 5)).cpu().numpy()
+    assert eq(xs, xs_o) and eq(J.cpu().numpy(), J_o)
+
+
+def _trajectories(B, T, scale_u, seed):
+    Mo = co.cartpole_model(T=T)
+    x0, us = co.cartpole_batch(B, T=T, seed_x=seed, seed_u=seed + 1)
+    us *= scale_u
+    xs, _ = co.rollout_cost(Mo, x0, us)
+    return Mo, xs, us
+
+
+@pytest.mark.parametrize("B,T,scale_u,mu", [(200, 100, 1.0, 1.0), (130, 100, 6.0, 0.0), (64, 15, 3.0, 1e3)])
+def test_backward_pass_bit_exact(hip, B, T, scale_u, mu):
+    Mo, xs, us = _trajectories(B, T, scale_u, 7)
+    mus = np.full(B, mu)
+    mus[::3] *= 0.5
+    ref = co.backward(Mo, co.Opts(), xs, us, mus)
+    M = hip_model(hip, Mo)
+    out = hip.backward_bm(M, hip.Opts(), B, hip.pack_bm(dev(xs)), hip.pack_bm(dev(us)), dev(mus))
+    k = hip.unpack_bm(out["k"], B, (T, 1)).cpu().numpy()
+    K = hip.unpack_bm(out["K"], B, (T, 1, 5)).cpu().numpy()
+    assert eq(k, ref["k"]) and eq(K, ref["K"])
+    dJ = out["dJ"].cpu().numpy()[:, :B]
+    info = out["info"].cpu().numpy()[:, :B]
+    assert eq(dJ[0], ref["dJ1"]) and eq(dJ[1], ref["dJ2"])
+    assert np.array_equal(info[0], ref["stopped_at"])
+    assert np.array_equal(info[1], ref["qp_iter"])
+    assert np.array_equal(info[2], ref["qp_backtrack"])
+    assert np.array_equal(info[3], ref["n_clamped"])
+    assert np.array_equal(out["qp_result"].cpu().numpy()[:, :B].T, ref["qp_result"])
+    assert np.array_equal(out["free"].cpu().numpy()[:, :B].T.reshape(B, T, 1), ref["free"])
+    # the workload really exercises the clamped / line-search-exhausted exits
+    if scale_u >= 3.0:
+        assert (ref["n_clamped"] > 0).any()
+
+
+def test_backward_pass_not_pd_break(hip):
+    """A large negative terminal weight makes Q_uu lose positive definiteness: the
+    reference breaks out of the sweep and leaves the earlier gains zero (ilqr_core.py:137-140)."""
+    T, B = 30, 70
+    Qt = -4000.0 * np.eye(5)
+    Mo = co.cartpole_model(T=T)
+    Mo = co.Model(co.MODEL_CARTPOLE, 5, 1, T, co.COST_QR, co.MATH_DET, True, Q=Mo.Q, R=Mo.R, Q_terminal=Qt,
+                  x_goal=Mo.x_goal, lower=Mo.lower, upper=Mo.upper)
+    x0, us = co.cartpole_batch(B, T=T, seed_x=9, seed_u=10)
+    xs, _ = co.rollout_cost(Mo, x0, us)
+    ref = co.backward(Mo, co.Opts(), xs, us, 1.0)
+    assert (ref["stopped_at"] >= 0).any()
+    M = hip_model(hip, Mo)
+    out = hip.backward_bm(M, hip.Opts(), B, hip.pack_bm(dev(xs)), hip.pack_bm(dev(us)), dev(np.full(B, 1.0)))
+    assert eq(hip.unpack_bm(out["k"], B, (T, 1)).cpu().numpy(), ref["k"])
+    assert eq(hip.unpack_bm(out["K"], B, (T, 1, 5)).cpu().numpy(), ref["K"])
+    assert np.array_equal(out["info"].cpu().numpy()[0, :B], ref["stopped_at"])
+    assert np.array_equal(out["qp_result"].cpu().numpy()[:, :B].T, ref["qp_result"])
+
+
+def test_forward_line_search_bit_exact(hip):
+    B, T = 150, 100
+    Mo, xs, us = _trajectories(B, T, 2.0, 11)
+    bw = co.backward(Mo, co.Opts(), xs, us, 1.0)
+    alphas = co.line_search_alphas(30)
+    xs_n, us_n, J_n = co.forward(Mo, alphas, xs, us, bw["k"], bw["K"])
+    M = hip_model(hip, Mo)
+    J, xs_new, us_new = hip.forward_ls_bm(M, B, alphas, hip.pack_bm(dev(xs)), hip.pack_bm(dev(us)),
+                                          hip.pack_bm(dev(bw["k"])), hip.pack_bm(dev(bw["K"])), want_traj=True)
+    assert eq(J.cpu().numpy()[:, :B].T, J_n)
+    xs_new = xs_new.cpu().numpy()[:, :, :B].transpose(2, 0, 1).reshape(B, 30, T + 1, 5)
+    us_new = us_new.cpu().numpy()[:, :, :B].transpose(2, 0, 1).reshape(B, 30, T, 1)
+    assert eq(xs_new, xs_n) and eq(us_new, us_n)
+
+
+def test_derivative_streams_bit_exact(hip):
+    B, T = 70, 100
+    Mo, xs, us = _trajectories(B, T, 2.0, 13)
+    M = hip_model(hip, Mo)
+    out = hip.deriv_bm(M, B, hip.pack_bm(dev(xs)), hip.pack_bm(dev(us)))
+    shapes = dict(fx=(T, 5, 5), fu=(T, 5, 1), lx=(T, 5), lu=(T, 1), lxx=(T, 5, 5), luu=(T, 1, 1), lux=(T, 1, 5),
+                  lxT=(5,), lxxT=(5, 5))
+    got = {k: hip.unpack_bm(out[k], B, shapes[k]).cpu().numpy() for k in shapes}
+    for b in range(0, B, 7):
+        ref = co.derivatives(Mo, xs[b], us[b])
+        for k in shapes:
+            assert eq(got[k][b], ref[k]), (b, k)
+
+
+def _check_solve(hip, Mo, x0, us0, max_iter, delta=None, k=None, K=None):
+    B = x0.shape[0]
+    ref = co.solve(Mo, co.Opts(max_iter=max_iter), x0, us0, delta=delta, k=k, K=K, nthreads=8)
+    M = hip_model(hip, Mo)
+    out = hip.solve(M, hip.Opts(max_iter=max_iter), dev(x0), dev(us0),
+                    delta=None if delta is None else dev(delta), k=None if k is None else dev(k),
+                    K=None if K is None else dev(K), trace=True)
+    torch.cuda.synchronize()
+    g = {key: out[key].cpu().numpy() for key in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K")}
+    assert np.array_equal(g["iters"], ref["iters"])
+    assert np.array_equal(g["status"], ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(g[key], ref[key]), key
+    tr = {key: out["trace"][key].cpu().numpy().T for key in out["trace"]}
+    for b in range(B):
+        it = ref["iters"][b]
+        for key in ("J", "mu", "delta"):
+            assert eq(tr[key][b, :it], ref["trace"][key][b, :it]), (b, key)
+        for key in ("accepted", "alpha_idx", "qp_iter", "qp_backtrack", "n_clamped", "stopped_at"):
+            assert np.array_equal(tr[key][b, :it], ref["trace"][key][b, :it]), (b, key)
+        assert (tr["accepted"][b, it:] == -1).all()
+    return ref, g
+
+
+def test_solve_bit_exact_swingup_batch(hip):
+    """C1-style batch (random swing-up states, bounds +-5 active)."""
+    B = 192
+    x0, us0 = co.cartpole_batch(B)
+    ref, _ = _check_solve(hip, co.cartpole_model(), x0, us0, 200)
+    assert (ref["status"] == 1).any() and (ref["status"] == 0).any()
+    assert (ref["trace"]["n_clamped"] > 0).any()
+
+
+def test_solve_bit_exact_ragged_and_warm_state(hip):
+    """B not a multiple of 64, short horizon, and a second call that reuses the
+    solver state (delta_, k_, K_) of the first, as the MPC driver does."""
+    B, T = 77, 15
+    Mo = co.cartpole_model(T=T, max_control=20.0, l=0.5, mpc=True)
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=5, seed_u=6)
+    ref, g = _check_solve(hip, Mo, x0, us0, 25)
+    us1 = np.concatenate([g["us"][:, 1:], g["us"][:, -1:]], axis=1)
+    _check_solve(hip, Mo, g["xs"][:, 1], us1, 10, delta=g["delta"], k=g["k"], K=g["K"])
+
+
+def test_solve_matches_reference_run_fixtures(hip, golden_dir):
+    """Against numbers recorded from the reference's own update_u."""
+    g = np.load(golden_dir + "/ref_cartpole_solve.npz")
+    Mo = co.cartpole_model()
+    M = hip_model(hip, Mo)
+    for i in range(int(g["n_problems"])):
+        p = "sympy_p%d_" % i
+        mi = int(g[p + "max_iter"])
+        out = hip.solve(M, hip.Opts(max_iter=mi), dev(g[p + "x0"][None]), dev(g[p + "us_init"][None]), trace=True)
+        it = int(out["iters"][0])
+        ref_J = g[p + "it_J"]
+        assert it == len(ref_J)
+        tr = {key: out["trace"][key].cpu().numpy()[:it, 0] for key in out["trace"]}
+        np.testing.assert_allclose(tr["J"], ref_J, rtol=1e-9)
+        assert np.array_equal(tr["accepted"].astype(bool), g[p + "it_accepted"])
+        assert np.array_equal(np.minimum(tr["alpha_idx"] + 1, 30), g[p + "it_n_forward"])
+        assert np.array_equal(tr["mu"], g[p + "it_mu"]) and np.array_equal(tr["delta"], g[p + "it_delta"])
+        assert bool(out["status"][0] == 1) == bool(g[p + "it_converged"][-1])
+        np.testing.assert_allclose(out["us"][0].cpu().numpy(), g[p + "us"], rtol=0, atol=1e-8)
+
+
+def test_boxqp_batched(hip, golden_dir):
+    g = np.load(golden_dir + "/ref_boxqp.npz")
+    for i in range(int(g["n_cases"])):
+        p = "q%d_" % i
+        m = g[p + "g"].shape[0]
+        x0 = g[p + "x0"][None] if bool(g[p + "has_x0"]) else None
+        O = hip.Opts(qp_step_dec=float(g[p + "step_dec"]))
+        ref = co.boxqp(g[p + "H"], g[p + "g"], g[p + "lower"], g[p + "upper"],
+                       None if x0 is None else x0, co.Opts(qp_step_dec=float(g[p + "step_dec"])))
+        out = hip.boxqp_batched(dev(g[p + "H"][None]), dev(g[p + "g"][None]), dev(g[p + "lower"][None]),
+                                dev(g[p + "upper"][None]), None if x0 is None else dev(x0), O)
+        assert int(out["result"][0]) == int(g[p + "result"]) == ref["result"][0], i
+        assert np.array_equal(out["free"][0].cpu().numpy().astype(bool), g[p + "free"])
+        assert eq(out["x"][0].cpu().numpy(), ref["x"][0])
+        d = int(out["hff_dim"][0])
+        assert d == ref["hff_dim"][0]
+        assert eq(np.tril(out["Hff"][0].cpu().numpy()[:d, :d]), np.tril(ref["Hff"][0][:d, :d]))
+        assert np.array_equal(out["counters"][0].cpu().numpy(),
+                              [ref["n_iter"][0], ref["n_factor"][0], ref["n_backtrack"][0]])
+        np.testing.assert_allclose(out["x"][0].cpu().numpy(), g[p + "x"], rtol=1e-9, atol=1e-12)
+
+
+def test_boxqp_batched_random_bit_exact(hip):
+    r = np.random.RandomState(3)
+    for m in (1, 2, 5, 8):
+        B = 500
+        A = r.randn(B, m, m)
+        H = np.einsum("bij,bkj->bik", A, A) + 0.05 * np.eye(m)
+        g_ = r.randn(B, m) * 3
+        lo, up = -r.uniform(0.05, 2, (B, m)), r.uniform(0.05, 2, (B, m))
+        x0 = np.where(r.uniform(size=(B, m)) < 0.3, up, r.randn(B, m))
+        ref = co.boxqp(H, g_, lo, up, x0, co.Opts())
+        out = hip.boxqp_batched(dev(H), dev(g_), dev(lo), dev(up), dev(x0), hip.Opts())
+        assert np.array_equal(out["result"].cpu().numpy(), ref["result"])
+        assert eq(out["x"].cpu().numpy(), ref["x"])
+        assert np.array_equal(out["free"].cpu().numpy().astype(bool), ref["free"])
+        assert np.array_equal(out["counters"].cpu().numpy()[:, 2], ref["n_backtrack"])
+
+
+def test_plant_step_bit_exact(hip):
+    r = np.random.RandomState(8)
+    st = r.uniform(-3, 3, (1000, 4))
+    u = r.uniform(-20, 20, 1000)
+    assert eq(hip.plant_step(dev(st), dev(u)).cpu().numpy(), co.plant_step(st, u))
+
+
+def test_full_size_batch_properties(hip):
+    """C1 at its full size (16384 problems): properties that need no oracle run."""
+    B = 16384
+    x0, us0 = co.cartpole_batch(B)
+    Mo = co.cartpole_model()
+    M = hip_model(hip, Mo)
+    out = hip.solve(M, hip.Opts(), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    iters, status = out["iters"].cpu().numpy(), out["status"].cpu().numpy()
+    J = out["J"].cpu().numpy()
+    trJ, acc = out["trace"]["J"].cpu().numpy(), out["trace"]["accepted"].cpu().numpy()
+    assert np.isfinite(J).all() and iters.min() >= 1 and iters.max() <= 200
+    assert set(np.unique(status)) <= {0, 1, 2}
+    # the cost never increases from one iteration to the next and the last entry is the result
+    for b in range(0, B, 97):
+        h = trJ[:iters[b], b]
+        assert (np.diff(h) <= 0).all() and h[-1] == J[b]
+        assert (acc[iters[b]:, b] == -1).all()
+    # the returned states are exactly the rollout of the returned controls, and J is their cost
+    xs_bm, J2 = hip.rollout_cost_bm(M, B, hip.pack_bm(out["xs"][:, 0].contiguous()), hip.pack_bm(out["us"]))
+    assert eq(hip.unpack_bm(xs_bm, B, (101, 5)).cpu().numpy(), out["xs"].cpu().numpy())
+    assert eq(J2.cpu().numpy(), J)
+    # control limits: the feed-forward part respects them; a sample agrees with the oracle bit for bit
+    idx = np.arange(0, B, 331)
+    ref = co.solve(Mo, co.Opts(), x0[idx], us0[idx], nthreads=8, trace=False)
+    assert np.array_equal(ref["iters"], iters[idx]) and eq(ref["J"], J[idx])
+    assert eq(ref["us"], out["us"].cpu().numpy()[idx])
+    # sharding: a slice solved alone gives the same bits as inside the big batch
+    lo, hi = 4096 + 17, 4096 + 17 + 1000
+    part = hip.solve(M, hip.Opts(), dev(x0[lo:hi]), dev(us0[lo:hi]))
+    assert eq(part["us"].cpu().numpy(), out["us"].cpu().numpy()[lo:hi])
+    assert np.array_equal(part["iters"].cpu().numpy(), iters[lo:hi])
