@@ -37,7 +37,8 @@ struct QRCostP {      // QRCost, ilqr/ilqr_cost.py:490-530, m = 1
 
 struct QPOptsP { // ilqr_core.py:154-155
     int max_iter;
-    int n_exhaust; // number of step reductions after which step < min_step (host-simulated)
+    int n_exhaust;    // number of step reductions after which step < min_step (host-simulated)
+    double step_last; // the step after n_exhaust reductions
     double min_grad, min_rel, step_dec, min_step, armijo;
 };
 
@@ -288,13 +289,36 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double g, dou
         double sdotg = (xc - x) * grad;
         double vc = qp_value1(H, g, xc);
         while ((vc - oldvalue) / (sdotg + 1e-10) < O.armijo) {
+            // Two exits that replace, without changing any result, the hundreds of
+            // reductions the reference spins through until step < minStep (:151-159).
+            // Both end exactly where the literal loop ends: result 2, n_exhaust
+            // reductions counted, candidate evaluated at the last step of the
+            // geometric sequence (step_last), both constants of (stepDec, minStep)
+            // computed on the host with the same rounded multiplications.
+            bool exhaust = false;
             if (xc == x) {
-                // Fixed point: x + step*search clamps (or rounds) back to x, and does so
-                // for every smaller step, so vc == oldvalue and sdotg == 0 from here on.
-                // The reference spins until step < minStep (:151-159); the number of
-                // reductions that takes is a constant of (stepDec, minStep), computed
-                // on the host with the same rounded multiplications.
+                // (a) fixed point: x + step*search clamps (or rounds) back to x, and does
+                // so for every smaller step; then vc == oldvalue, sdotg == 0, ratio == 0.
+                exhaust = true;
+            } else if (nstep >= 20 && (nstep & 3) == 0 && O.armijo > 0.0) {
+                // (b) the 1e-10 in the denominator makes the test unsatisfiable once the
+                // step is tiny: with d = xc' - x for any later candidate, |d| <= D, so
+                //   sdotg' + 1e-10 >= 1e-10 - 1.001 D |grad|  >= 0.5e-10          (A)
+                //   vc' - oldvalue <= D |grad| + H D^2 / 2 + rounding =: N         (B)
+                // (rounding of the two quadratic evaluations is below
+                // 1e-15 (X |g| + H X^2), X = |x| + D).  If N <= 0.49e-10 * Armijo every
+                // later ratio is below Armijo whatever the rounding of the division.
+                double ax = fabs(x), ag = fabs(grad);
+                double D = 1.001 * (step * fabs(search)) + 4e-16 * ax;
+                double X = ax + D;
+                double gt = ag + 5e-16 * (fabs(g) + fabs(H * x));
+                double N = 1.001 * (D * gt + 0.5 * H * D * D) + 1e-15 * (X * fabs(g) + H * X * X);
+                exhaust = (D * ag <= 0.49e-10) && (N <= 0.49e-10 * O.armijo);
+            }
+            if (exhaust) {
                 nstep = O.n_exhaust;
+                xc = clamp1(lo, hi, x + O.step_last * search);
+                vc = qp_value1(H, g, xc);
                 result = 2;
                 break;
             }

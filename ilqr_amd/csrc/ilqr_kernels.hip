@@ -719,6 +719,44 @@ __global__ __launch_bounds__(WAVE) void k_boxqp(QPOptsP O, int64_t B, int m, con
     cnt_out[q * 3 + 2] = n_bt;
 }
 
+// boxQP for m = 1 through the same in-register routine the backward pass uses.
+__global__ __launch_bounds__(256) void k_boxqp1(QPOptsP O, int64_t B, const double* __restrict__ H,
+                                                const double* __restrict__ g, const double* __restrict__ lower,
+                                                const double* __restrict__ upper, const double* __restrict__ x0,
+                                                double* __restrict__ x_out, int32_t* __restrict__ result_out,
+                                                double* __restrict__ Hff_out, int32_t* __restrict__ hd_out,
+                                                int32_t* __restrict__ free_out, int32_t* __restrict__ cnt_out)
+{
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= B)
+        return;
+    QP1Out out;
+    double lo = lower[q], hi = upper[q];
+    double xs = x0 ? x0[q] : (lo + hi) / 2;
+    boxqp1(O, H[q], g[q], lo, hi, xs, out);
+    if (!(fabs(H[q]) < __builtin_inf()) && O.max_iter > 0) {
+        // non-finite H: the first pass either finds everything clamped (:92) or
+        // np.linalg.eigvals raises (:103); boxqp1 is written for the finite H the
+        // backward pass guarantees, so that case is decided here
+        double xq = clamp1(lo, hi, xs);
+        double grad = g[q] + H[q] * xq;
+        bool cl = ((xq == lo) && (grad > 0.0)) || ((xq == hi) && (grad < 0.0));
+        out.x = xq;
+        out.result = cl ? 6 : -99;
+        out.free_ = !cl;
+        out.hff = 1.0;
+        out.n_iter = out.n_factor = out.n_backtrack = 0;
+    }
+    x_out[q] = out.x;
+    result_out[q] = out.result;
+    Hff_out[q] = out.hff;
+    hd_out[q] = 1;
+    free_out[q] = out.free_ ? 1 : 0;
+    cnt_out[q * 3 + 0] = out.n_iter;
+    cnt_out[q * 3 + 1] = out.n_factor;
+    cnt_out[q * 3 + 2] = out.n_backtrack;
+}
+
 // -------------------------------------------------------------- plant step
 
 // CartPoleContinuousEnv._state_eq, ilqr/cartpole_gym.py:60-72
@@ -819,6 +857,7 @@ int fill_qp(const ilqr_opts* o, QPOptsP& q)
         ++n;
     } while (!(step < o->qp_min_step) && n < 1000000);
     q.n_exhaust = n;
+    q.step_last = step;
     return ILQR_OK;
 }
 
@@ -1041,8 +1080,12 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
     int rc = fill_qp(opts, q);
     if (rc != ILQR_OK)
         return rc;
-    hipLaunchKernelGGL(k_boxqp, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, as_stream(stream), q,
-                       B, (int)m, H, g, lower, upper, x0, x, result, Hff, hff_dim, free_mask, counters);
+    if (m == 1)
+        hipLaunchKernelGGL(k_boxqp1, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, as_stream(stream), q, B, H,
+                           g, lower, upper, x0, x, result, Hff, hff_dim, free_mask, counters);
+    else
+        hipLaunchKernelGGL(k_boxqp, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, as_stream(stream), q,
+                           B, (int)m, H, g, lower, upper, x0, x, result, Hff, hff_dim, free_mask, counters);
     return hip_status(hipGetLastError());
 }
 

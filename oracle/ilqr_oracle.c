@@ -591,6 +591,13 @@ static int boxqp(int m, const double *H, const double *g, const double *lower, c
     return 0;
 }
 
+/* Optional capture of every boxQP call made by the backward pass: rows of
+ * (H, g, lower, upper, x0) for m = 1.  Single-threaded diagnostic use only. */
+static double *g_qp_capture = NULL;
+static long g_qp_capture_cap = 0, g_qp_capture_n = 0;
+void oracle_set_qp_capture(double *buf, long cap) { g_qp_capture = buf; g_qp_capture_cap = cap; g_qp_capture_n = 0; }
+long oracle_get_qp_capture_count(void) { return g_qp_capture_n; }
+
 /* ------------------------------------------------------- backward pass */
 
 typedef struct {
@@ -716,6 +723,10 @@ static int backward_pass(const oracle_model *P, const oracle_opts *O, const doub
             for (int a = 0; a < m; ++a) {
                 lo[a] = P->lower[a] - u[a];
                 hi[a] = P->upper[a] - u[a];
+            }
+            if (g_qp_capture && m == 1 && g_qp_capture_n < g_qp_capture_cap) {
+                double *row = g_qp_capture + 5 * g_qp_capture_n++;
+                row[0] = Quu[0]; row[1] = Qu[0]; row[2] = lo[0]; row[3] = hi[0]; row[4] = ki[0];
             }
             if (boxqp(m, Quu, Qu, lo, hi, ki, O, xq, &result, Hff, &hd, freev, &cnt) != 0)
                 return -1;

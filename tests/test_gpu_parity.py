@@ -297,3 +297,34 @@ def test_full_size_batch_properties(hip):
     part = hip.solve(M, hip.Opts(), dev(x0[lo:hi]), dev(us0[lo:hi]))
     assert eq(part["us"].cpu().numpy(), out["us"].cpu().numpy()[lo:hi])
     assert np.array_equal(part["iters"].cpu().numpy(), iters[lo:hi])
+
+
+def test_boxqp1_on_captured_backward_pass_inputs(hip):
+    """Every boxQP call (Q_uu, Q_u, bounds, warm start) made by the backward passes of
+    real solves, replayed through the in-register m = 1 routine: the early exits that
+    replace the reference's long Armijo spin must not change a bit or a counter."""
+    import ctypes as C
+    L = co.lib()
+    cap = 700000
+    buf = np.zeros((cap, 5))
+    L.oracle_get_qp_capture_count.restype = C.c_long
+    L.oracle_set_qp_capture(buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(cap))
+    try:
+        x0, us0 = co.cartpole_batch(48, seed_x=31, seed_u=32)
+        co.solve(co.cartpole_model(), co.Opts(), x0, us0, nthreads=1, trace=False)
+        n = L.oracle_get_qp_capture_count()
+    finally:
+        L.oracle_set_qp_capture(None, C.c_long(0))
+    qp = buf[:n]
+    assert n > 100000
+    ref = co.boxqp(qp[:, 0].reshape(-1, 1, 1), qp[:, 1:2], qp[:, 2:3], qp[:, 3:4], qp[:, 4:5], co.Opts())
+    assert (ref["n_backtrack"] >= 481).sum() > 100  # the spin really occurs in this workload
+    out = hip.boxqp_batched(dev(qp[:, 0].reshape(-1, 1, 1)), dev(qp[:, 1:2]), dev(qp[:, 2:3]), dev(qp[:, 3:4]),
+                            dev(qp[:, 4:5]), hip.Opts())
+    assert np.array_equal(out["result"].cpu().numpy(), ref["result"])
+    assert eq(out["x"].cpu().numpy(), ref["x"])
+    assert np.array_equal(out["free"].cpu().numpy().astype(bool), ref["free"])
+    cnt = out["counters"].cpu().numpy()
+    assert np.array_equal(cnt[:, 0], ref["n_iter"]) and np.array_equal(cnt[:, 1], ref["n_factor"])
+    assert np.array_equal(cnt[:, 2], ref["n_backtrack"])
+    assert eq(out["Hff"].cpu().numpy()[:, 0, 0], ref["Hff"][:, 0, 0])
