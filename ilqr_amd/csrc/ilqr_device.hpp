@@ -9,8 +9,9 @@
 // explicit fma(); triangular solves multiply by the reciprocal of the diagonal;
 // scalar expressions of the reference (dynamics, cost totals, schedules,
 // ratios) are plain unfused operations in source order.  Structural zeros and
-// ones of the cart-pole Jacobian are skipped: x*1 and x+0 are exact, so only the
-// sign of an exact zero can differ from a dense evaluation.
+// ones (of the cart-pole Jacobian, and of a diagonal cost matrix) are skipped:
+// x*1 and x+0 are exact, so only the sign of an exact zero can differ from a
+// dense evaluation.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -19,6 +20,24 @@
 namespace ilqr {
 
 constexpr int NX = 5;
+
+// Pin a wave-uniform value in vector registers.  Kernel arguments live in scalar
+// registers; the cost matrices, model constants and options together exceed the
+// ~100 SGPRs a wave has, and the compiler then spills them lane by lane
+// (v_writelane / v_readlane around every use).  There are VGPRs to spare.
+__device__ __forceinline__ double vreg(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// Keep a value's registers occupied up to this point.  A global store holds its
+// data registers until it completes (~2 us); if the allocator hands them to the
+// next computation, the hardware-required wait for the store lands in the middle
+// of the step.  Results are therefore parked in "pending" variables that are
+// stored at the START of the next step and kept alive (this anchor) to its END,
+// so that by the time they are overwritten the store has long retired.
+__device__ __forceinline__ void keep_alive(double x) { asm volatile("" ::"v"(x)); }
 
 // ---- kernel-argument structs (filled on the host, passed by value) ---------
 
@@ -42,6 +61,18 @@ struct QPOptsP { // ilqr_core.py:154-155
     double min_grad, min_rel, step_dec, min_step, armijo;
 };
 
+__device__ __forceinline__ QPOptsP qp_opts_in_vgprs(const QPOptsP& o)
+{
+    QPOptsP v = o;
+    v.step_last = vreg(o.step_last);
+    v.min_grad = vreg(o.min_grad);
+    v.min_rel = vreg(o.min_rel);
+    v.step_dec = vreg(o.step_dec);
+    v.min_step = vreg(o.min_step);
+    v.armijo = vreg(o.armijo);
+    return v;
+}
+
 struct SolveOptsP {
     int max_iter, n_alpha;
     double tol, scale, mu_min, mu_max, delta0;
@@ -51,21 +82,21 @@ struct SolveOptsP {
 
 // ---- cart-pole dynamics -----------------------------------------------------
 
-struct CartpoleC { // constants derived once per thread
+struct CartpoleC { // constants derived once per thread, held in VGPRs
     double dt, g, l, mp, M, mpl, invM, mplM;
 };
 
 __device__ __forceinline__ CartpoleC cartpole_consts(const CartpoleP& p)
 {
     CartpoleC c;
-    c.dt = p.dt;
-    c.g = p.g;
-    c.l = p.l;
-    c.mp = p.mp;
-    c.M = p.mc + p.mp;
-    c.mpl = p.mp * p.l;
-    c.invM = 1.0 / c.M;
-    c.mplM = c.mpl * c.invM;
+    c.dt = vreg(p.dt);
+    c.g = vreg(p.g);
+    c.l = vreg(p.l);
+    c.mp = vreg(p.mp);
+    c.M = vreg(p.mc + p.mp);
+    c.mpl = vreg(p.mp * p.l);
+    c.invM = vreg(1.0 / c.M);
+    c.mplM = vreg(c.mpl * c.invM);
     return c;
 }
 
@@ -151,62 +182,148 @@ __device__ __forceinline__ void cartpole_jac(const CartpoleC& P, const double (&
     J.b4 = thdd_F * dt;
 }
 
-// ---- QRCost -----------------------------------------------------------------
+// ---- QRCost (ilqr/ilqr_cost.py:486-632), two evaluators with one interface ----
+//
+//   l(x, u), l_terminal(x)        :532-553  (value carries the 1/2 its gradients lack)
+//   lx(x, out), lx_terminal       :555-569  x_diff^T (Q + Q^T)
+//   lu(u)                         :571-587
+//   lxx(a, b), lxx_terminal(a, b) :589-601
+//   add_lxx(a, b, v) = lxx(a, b) + v
+//   luu()                         :617-632
+//
+// DenseQR reads the full matrices from the kernel arguments.  DiagQR is used when
+// Q and Q_terminal are diagonal (the host checks): it keeps the ten diagonal
+// entries in VGPRs and evaluates exactly the non-zero terms of the dense chains.
 
-// (v^T M) . v in the order of x_diff.T.dot(Q).dot(x_diff), ilqr_cost.py:547
-__device__ __forceinline__ double quad5(const double (&v)[NX], const double* M)
-{
-    double tot = 0.0;
+struct DenseQR {
+    const QRCostP& C;
+    __device__ __forceinline__ explicit DenseQR(const QRCostP& c) : C(c) {}
+
+    __device__ __forceinline__ double quad(const double (&v)[NX], const double* M) const
+    {
+        // (v^T M) . v in the order of x_diff.T.dot(Q).dot(x_diff), :547
+        double tot = 0.0;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
-        double acc = v[0] * M[j];
+        for (int j = 0; j < NX; ++j) {
+            double acc = v[0] * M[j];
 #pragma unroll
-        for (int i = 1; i < NX; ++i)
-            acc = fma(v[i], M[i * NX + j], acc);
-        tot = (j == 0) ? acc * v[0] : fma(acc, v[j], tot);
+            for (int i = 1; i < NX; ++i)
+                acc = fma(v[i], M[i * NX + j], acc);
+            tot = (j == 0) ? acc * v[0] : fma(acc, v[j], tot);
+        }
+        return tot;
     }
-    return tot;
-}
-
-// QRCost.l, ilqr_cost.py:532-553 (the value carries the 1/2 its gradients lack)
-__device__ __forceinline__ double qr_l(const QRCostP& C, const double (&x)[NX], double u)
-{
-    double xd[NX];
+    __device__ __forceinline__ void diff(const double (&x)[NX], double (&xd)[NX]) const
+    {
 #pragma unroll
-    for (int i = 0; i < NX; ++i)
-        xd[i] = x[i] - C.xg[i];
-    double sx = quad5(xd, C.Q) * 0.5;
-    double ud = u - C.ug;
-    double su = ((ud * C.R) * ud) * 0.5;
-    return sx + su;
-}
-
-__device__ __forceinline__ double qr_l_terminal(const QRCostP& C, const double (&x)[NX])
-{
-    double xd[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i)
-        xd[i] = x[i] - C.xg[i];
-    return quad5(xd, C.Qt) * 0.5;
-}
-
-// QRCost.l_x = x_diff^T (Q + Q^T), ilqr_cost.py:555-569
-__device__ __forceinline__ void qr_lx(const double* QQ, const double* xg, const double (&x)[NX],
-                                      double (&out)[NX])
-{
-    double xd[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i)
-        xd[i] = x[i] - xg[i];
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-        double acc = xd[0] * QQ[j];
-#pragma unroll
-        for (int a = 1; a < NX; ++a)
-            acc = fma(xd[a], QQ[a * NX + j], acc);
-        out[j] = acc;
+        for (int i = 0; i < NX; ++i)
+            xd[i] = x[i] - C.xg[i];
     }
-}
+    __device__ __forceinline__ double l(const double (&x)[NX], double u) const
+    {
+        double xd[NX];
+        diff(x, xd);
+        double sx = quad(xd, C.Q) * 0.5;
+        double ud = u - C.ug;
+        double su = ((ud * C.R) * ud) * 0.5;
+        return sx + su;
+    }
+    __device__ __forceinline__ double l_terminal(const double (&x)[NX]) const
+    {
+        double xd[NX];
+        diff(x, xd);
+        return quad(xd, C.Qt) * 0.5;
+    }
+    __device__ __forceinline__ void lx_with(const double* QQ, const double (&x)[NX], double (&out)[NX]) const
+    {
+        double xd[NX];
+        diff(x, xd);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            double acc = xd[0] * QQ[j];
+#pragma unroll
+            for (int a = 1; a < NX; ++a)
+                acc = fma(xd[a], QQ[a * NX + j], acc);
+            out[j] = acc;
+        }
+    }
+    __device__ __forceinline__ void lx(const double (&x)[NX], double (&out)[NX]) const { lx_with(C.QQ, x, out); }
+    __device__ __forceinline__ void lx_terminal(const double (&x)[NX], double (&out)[NX]) const
+    {
+        lx_with(C.QQt, x, out);
+    }
+    __device__ __forceinline__ double lu(double u) const { return (u - C.ug) * C.RR; }
+    __device__ __forceinline__ double lxx(int a, int b) const { return C.QQ[a * NX + b]; }
+    __device__ __forceinline__ double lxx_terminal(int a, int b) const { return C.QQt[a * NX + b]; }
+    __device__ __forceinline__ double add_lxx(int a, int b, double v) const { return C.QQ[a * NX + b] + v; }
+    __device__ __forceinline__ double luu() const { return C.RR; }
+};
+
+struct DiagQR {
+    double q[NX], qt[NX], qq[NX], qqt[NX], xg[NX], R, RR, ug;
+    __device__ __forceinline__ explicit DiagQR(const QRCostP& C)
+    {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            q[i] = vreg(C.Q[i * NX + i]);
+            qt[i] = vreg(C.Qt[i * NX + i]);
+            qq[i] = vreg(C.QQ[i * NX + i]);
+            qqt[i] = vreg(C.QQt[i * NX + i]);
+            xg[i] = vreg(C.xg[i]);
+        }
+        R = vreg(C.R);
+        RR = vreg(C.RR);
+        ug = vreg(C.ug);
+    }
+    __device__ __forceinline__ double quad(const double (&v)[NX], const double (&d)[NX]) const
+    {
+        // the dense chain with every off-diagonal product dropped: column j of
+        // v^T M is v[j] * d[j], then the running dot with v
+        double tot = (v[0] * d[0]) * v[0];
+#pragma unroll
+        for (int j = 1; j < NX; ++j)
+            tot = fma(v[j] * d[j], v[j], tot);
+        return tot;
+    }
+    __device__ __forceinline__ void diff(const double (&x)[NX], double (&xd)[NX]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xd[i] = x[i] - xg[i];
+    }
+    __device__ __forceinline__ double l(const double (&x)[NX], double u) const
+    {
+        double xd[NX];
+        diff(x, xd);
+        double sx = quad(xd, q) * 0.5;
+        double ud = u - ug;
+        double su = ((ud * R) * ud) * 0.5;
+        return sx + su;
+    }
+    __device__ __forceinline__ double l_terminal(const double (&x)[NX]) const
+    {
+        double xd[NX];
+        diff(x, xd);
+        return quad(xd, qt) * 0.5;
+    }
+    __device__ __forceinline__ void lx(const double (&x)[NX], double (&out)[NX]) const
+    {
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            out[j] = (x[j] - xg[j]) * qq[j];
+    }
+    __device__ __forceinline__ void lx_terminal(const double (&x)[NX], double (&out)[NX]) const
+    {
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            out[j] = (x[j] - xg[j]) * qqt[j];
+    }
+    __device__ __forceinline__ double lu(double u) const { return (u - ug) * RR; }
+    __device__ __forceinline__ double lxx(int a, int b) const { return a == b ? qq[a] : 0.0; }
+    __device__ __forceinline__ double lxx_terminal(int a, int b) const { return a == b ? qqt[a] : 0.0; }
+    __device__ __forceinline__ double add_lxx(int a, int b, double v) const { return a == b ? qq[a] + v : v; }
+    __device__ __forceinline__ double luu() const { return RR; }
+};
 
 // ---- boxQP, m = 1 -------------------------------------------------------------
 
@@ -221,6 +338,29 @@ __device__ __forceinline__ double qp_value1(double H, double g, double x)
 {
     // np.dot(x.T, g) + 0.5 * np.dot(np.dot(x.T, H), x), ilqr_boxQP.py:62
     return x * g + 0.5 * ((x * H) * x);
+}
+
+// (num / den) < a, decided without the division whenever the outcome is not within
+// rounding distance of the threshold: for den > 0, num < a*den*(1 - 1e-12) implies
+// the correctly rounded quotient is below a, num > a*den*(1 + 1e-12) implies it is
+// not (rounding is monotone and a is representable); signs flip for den < 0.
+// Anything else (near ties, den == 0, NaN, inf, a <= 0) takes the real division,
+// behind a wave-uniform branch so that the common path is straight-line code.
+__device__ __forceinline__ bool quotient_below(double num, double den, double a)
+{
+    double p = a * den;
+    double tol = fabs(p) * 1e-12;
+    bool lo = num < p - tol, hi = num > p + tol;
+    bool pos = den > 0.0, neg = den < 0.0;
+    bool usable = a > 0.0; // a <= 0 would let an underflowing quotient change the answer
+    bool sure_true = usable & ((pos & lo) | (neg & hi));
+    bool sure_false = usable & ((pos & hi) | (neg & lo));
+    bool below = sure_true;
+    if (__ballot(!(sure_true | sure_false)) != 0ull) {
+        bool exact = (num / den) < a;
+        below = (sure_true | sure_false) ? sure_true : exact;
+    }
+    return below;
 }
 
 struct QP1Out {
@@ -283,54 +423,47 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double g, dou
         double sol = (rhs * rdiag) * rdiag;
         double search = sol * -1 - x;
 
+        // Armijo line search (:140-159), written with selects and a single loop exit.
+        // Two early exits replace, without changing any result, the hundreds of
+        // reductions the reference spins through until step < minStep when the test
+        // has become unsatisfiable.  Both end exactly where the literal loop ends:
+        // result 2, n_exhaust reductions counted, candidate evaluated at the last step
+        // of the geometric sequence (step_last); n_exhaust and step_last are constants
+        // of (stepDec, minStep) computed on the host with the same rounded products.
+        //  (a) fixed point: x + step*search clamps (or rounds) back to x, and does so
+        //      for every smaller step; then vc == oldvalue, sdotg == 0, ratio == 0.
+        //  (b) the 1e-10 in the denominator: with d = xc' - x for any later candidate,
+        //      |d| <= D, so  sdotg' + 1e-10 >= 1e-10 - 1.001 D |grad| >= 0.5e-10  and
+        //      vc' - oldvalue <= D |grad| + H D^2 / 2 + rounding =: N  (rounding of the
+        //      two quadratic evaluations is below 1e-15 (X |g| + H X^2), X = |x| + D).
+        //      If N <= 0.49e-10 * Armijo every later ratio is below Armijo whatever the
+        //      rounding of the division.  Checked every 4th reduction from the 20th on.
         double step = 1.0;
         int nstep = 0;
         double xc = clamp1(lo, hi, x + step * search);
         double sdotg = (xc - x) * grad;
         double vc = qp_value1(H, g, xc);
-        while ((vc - oldvalue) / (sdotg + 1e-10) < O.armijo) {
-            // Two exits that replace, without changing any result, the hundreds of
-            // reductions the reference spins through until step < minStep (:151-159).
-            // Both end exactly where the literal loop ends: result 2, n_exhaust
-            // reductions counted, candidate evaluated at the last step of the
-            // geometric sequence (step_last), both constants of (stepDec, minStep)
-            // computed on the host with the same rounded multiplications.
-            bool exhaust = false;
-            if (xc == x) {
-                // (a) fixed point: x + step*search clamps (or rounds) back to x, and does
-                // so for every smaller step; then vc == oldvalue, sdotg == 0, ratio == 0.
-                exhaust = true;
-            } else if (nstep >= 20 && (nstep & 3) == 0 && O.armijo > 0.0) {
-                // (b) the 1e-10 in the denominator makes the test unsatisfiable once the
-                // step is tiny: with d = xc' - x for any later candidate, |d| <= D, so
-                //   sdotg' + 1e-10 >= 1e-10 - 1.001 D |grad|  >= 0.5e-10          (A)
-                //   vc' - oldvalue <= D |grad| + H D^2 / 2 + rounding =: N         (B)
-                // (rounding of the two quadratic evaluations is below
-                // 1e-15 (X |g| + H X^2), X = |x| + D).  If N <= 0.49e-10 * Armijo every
-                // later ratio is below Armijo whatever the rounding of the division.
+        bool more = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo);
+        int trip = 0; // same for every lane still in the loop
+        while (more) {
+            bool exhaust = (xc == x);
+            if (trip >= 20 && (trip & 3) == 0) {
                 double ax = fabs(x), ag = fabs(grad);
                 double D = 1.001 * (step * fabs(search)) + 4e-16 * ax;
                 double X = ax + D;
                 double gt = ag + 5e-16 * (fabs(g) + fabs(H * x));
                 double N = 1.001 * (D * gt + 0.5 * H * D * D) + 1e-15 * (X * fabs(g) + H * X * X);
-                exhaust = (D * ag <= 0.49e-10) && (N <= 0.49e-10 * O.armijo);
+                exhaust = exhaust | ((O.armijo > 0.0) & (D * ag <= 0.49e-10) & (N <= 0.49e-10 * O.armijo));
             }
-            if (exhaust) {
-                nstep = O.n_exhaust;
-                xc = clamp1(lo, hi, x + O.step_last * search);
-                vc = qp_value1(H, g, xc);
-                result = 2;
-                break;
-            }
-            step = step * O.step_dec;
-            ++nstep;
+            step = exhaust ? O.step_last : step * O.step_dec;
+            nstep = exhaust ? O.n_exhaust : nstep + 1;
+            ++trip;
             xc = clamp1(lo, hi, x + step * search);
             vc = qp_value1(H, g, xc);
             sdotg = (xc - x) * grad;
-            if (step < O.min_step) {
-                result = 2;
-                break;
-            }
+            bool ended = exhaust | (step < O.min_step);
+            result = ended ? 2 : result;
+            more = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo) & !ended;
         }
         n_bt += nstep;
         x = xc;
@@ -357,13 +490,16 @@ struct BwAcc {          // running state of one backward sweep
 
 enum { BW_OK = 0, BW_NOT_PD = 1, BW_LINALG = 2 };
 
-__device__ __forceinline__ void bw_init(const QRCostP& C, const double (&xT)[NX], BwAcc& S)
+template <class Cost>
+__device__ __forceinline__ void bw_init(const Cost& C, const double (&xT)[NX], BwAcc& S)
 {
     // V_x, V_xx = terminal l_x, l_xx (ilqr_core.py:120-121)
-    qr_lx(C.QQt, C.xg, xT, S.Vx);
+    C.lx_terminal(xT, S.Vx);
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i)
-        S.Vxx[i] = C.QQt[i];
+    for (int a = 0; a < NX; ++a)
+#pragma unroll
+        for (int b = 0; b < NX; ++b)
+            S.Vxx[a * NX + b] = C.lxx_terminal(a, b);
     S.dJ1 = 0.0;
     S.dJ2 = 0.0;
     S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
@@ -374,14 +510,15 @@ __device__ __forceinline__ void bw_init(const QRCostP& C, const double (&xT)[NX]
 // Returns BW_OK (k_out, K_out, S updated), BW_NOT_PD (the reference prints,
 // warns and breaks, :137-140) or BW_LINALG (eigvals would raise on a non-finite
 // Q_uu, :291).
-__device__ __forceinline__ int bw_step(const QRCostP& C, const QPOptsP& QO, const CartpoleJac& J,
-                                       double dt, const double (&x)[NX], double u, double mu,
-                                       double lower, double upper, BwAcc& S, double& k_out,
-                                       double (&K_out)[NX], int& qp_result, bool& qp_free)
+template <class Cost>
+__device__ __forceinline__ int bw_step(const Cost& C, const QPOptsP& QO, const CartpoleJac& J, double dt,
+                                       const double (&x)[NX], double u, double mu, double lower,
+                                       double upper, BwAcc& S, double& k_out, double (&K_out)[NX],
+                                       int& qp_result, bool& qp_free)
 {
     double lx[NX];
-    qr_lx(C.QQ, C.xg, x, lx);
-    double lu = (u - C.ug) * C.RR; // u_diff^T (R + R^T), ilqr_cost.py:586-587
+    C.lx(x, lx);
+    double lu = C.lu(u); // u_diff^T (R + R^T), ilqr_cost.py:586-587
 
     // column c (>= 2) of f_x is [0, a[0][c-2], a[1][c-2], a[2][c-2], a[3][c-2]]
     const double(&A)[4][3] = J.a;
@@ -420,15 +557,15 @@ __device__ __forceinline__ int bw_step(const QRCostP& C, const QPOptsP& QO, cons
     double Qxx[NX * NX];
 #pragma unroll
     for (int a = 0; a < NX; ++a) {
-        Qxx[a * NX + 0] = C.QQ[a * NX + 0] + M1[a * NX + 0];
-        Qxx[a * NX + 1] = C.QQ[a * NX + 1] + (M1[a * NX + 0] * dt + M1[a * NX + 1]);
+        Qxx[a * NX + 0] = C.add_lxx(a, 0, M1[a * NX + 0]);
+        Qxx[a * NX + 1] = C.add_lxx(a, 1, M1[a * NX + 0] * dt + M1[a * NX + 1]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double acc = M1[a * NX + 1] * A[0][c];
             acc = fma(M1[a * NX + 2], A[1][c], acc);
             acc = fma(M1[a * NX + 3], A[2][c], acc);
             acc = fma(M1[a * NX + 4], A[3][c], acc);
-            Qxx[a * NX + 2 + c] = C.QQ[a * NX + 2 + c] + acc;
+            Qxx[a * NX + 2 + c] = C.add_lxx(a, 2 + c, acc);
         }
     }
 
@@ -451,7 +588,7 @@ __device__ __forceinline__ int bw_step(const QRCostP& C, const QPOptsP& QO, cons
         acc = fma(M2[4], A[3][c], acc);
         Qux[2 + c] = 0.0 + acc;
     }
-    double Quu = C.RR + fma(M2[4], J.b4, M2[1] * J.b1);
+    double Quu = C.luu() + fma(M2[4], J.b4, M2[1] * J.b1);
 
     // np.all(np.linalg.eigvals(Q_uu) > 0), then cholesky   (:137-141)
     if (!(fabs(Quu) < __builtin_inf()))
@@ -493,11 +630,15 @@ __device__ __forceinline__ int bw_step(const QRCostP& C, const QPOptsP& QO, cons
         for (int b = 0; b < NX; ++b)
             Vn[a * NX + b] = ((Qxx[a * NX + b] + T1[a] * K[b]) + K[a] * Qux[b]) + Qux[a] * K[b];
     }
+    // 0.5 * (V + V^T): entries (a, b) and (b, a) are the same sum, computed once
 #pragma unroll
     for (int a = 0; a < NX; ++a)
 #pragma unroll
-        for (int b = 0; b < NX; ++b)
-            S.Vxx[a * NX + b] = 0.5 * (Vn[a * NX + b] + Vn[b * NX + a]);
+        for (int b = a; b < NX; ++b) {
+            double v = 0.5 * (Vn[a * NX + b] + Vn[b * NX + a]);
+            S.Vxx[a * NX + b] = v;
+            S.Vxx[b * NX + a] = v;
+        }
 
     // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)                 (:175-176)
     S.dJ1 = S.dJ1 + kk * Qu;

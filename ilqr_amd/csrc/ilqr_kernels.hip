@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/ilqr_hip.h"
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256) void k_unpack(const double* __restrict__ srcA,
 // ------------------------------------------------------- rollout and cost
 
 // _dynamics_rollout + _trajectory_cost (ilqr_core.py:69-83, :230-239)
-__global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP C, int T, int64_t B,
+template <class Cost>
+__global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP Cp, int T, int64_t B,
                                                        int64_t ld, const double* __restrict__ x0,
                                                        const double* __restrict__ us,
                                                        double* __restrict__ xs, double* __restrict__ Jout)
@@ -103,27 +105,28 @@ __global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP C, 
     if (b >= B)
         return;
     CartpoleC P = cartpole_consts(mp);
+    Cost C(Cp);
     double x[NX], xn[NX];
     load5(x0, ld, 0, b, x);
     double J = 0.0;
     for (int t = 0; t < T; ++t) {
         double u = us[(int64_t)t * ld + b];
         store5(xs, ld, (int64_t)t * NX, b, x);
-        J = J + qr_l(C, x, u);
+        J = J + C.l(x, u);
         cartpole_f(P, x, u, xn);
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             x[i] = xn[i];
     }
     store5(xs, ld, (int64_t)T * NX, b, x);
-    Jout[b] = J + qr_l_terminal(C, x);
+    Jout[b] = J + C.l_terminal(x);
 }
 
 // ------------------------------------------------- derivative tensor stream
 
 // One thread per (problem, step): f_x, f_u, l_x, l_u, l_xx, l_uu, l_ux as dense
 // batch-minor streams (what _compute_Q_terms asks the model for, ilqr_core.py:189-198).
-__global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP C, int T, int64_t B, int64_t ld,
+__global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP Cp, int T, int64_t B, int64_t ld,
                                                const double* __restrict__ xs,
                                                const double* __restrict__ us, ilqr_deriv_bm_t o)
 {
@@ -132,14 +135,15 @@ __global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP C, int T, i
     if (b >= B)
         return;
     CartpoleC P = cartpole_consts(mp);
+    DenseQR C(Cp);
     double x[NX];
     load5(xs, ld, (int64_t)t * NX, b, x);
     if (t == T) { // terminal l_x, l_xx (ilqr_core.py:120-121)
         double lx[NX];
-        qr_lx(C.QQt, C.xg, x, lx);
+        C.lx_terminal(x, lx);
         store5(o.lxT, ld, 0, b, lx);
         for (int i = 0; i < NX * NX; ++i)
-            o.lxxT[(int64_t)i * ld + b] = C.QQt[i];
+            o.lxxT[(int64_t)i * ld + b] = Cp.QQt[i];
         return;
     }
     double u = us[(int64_t)t * ld + b];
@@ -164,16 +168,16 @@ __global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP C, int T, i
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) {
         o.fx[(base + i) * ld + b] = fx[i];
-        o.lxx[(base + i) * ld + b] = C.QQ[i];
+        o.lxx[(base + i) * ld + b] = Cp.QQ[i];
     }
     double fu[NX] = {0.0, J.b1, 0.0, 0.0, J.b4};
     double lx[NX], zero[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    qr_lx(C.QQ, C.xg, x, lx);
+    C.lx(x, lx);
     store5(o.fu, ld, (int64_t)t * NX, b, fu);
     store5(o.lx, ld, (int64_t)t * NX, b, lx);
     store5(o.lux, ld, (int64_t)t * NX, b, zero);
-    o.lu[(int64_t)t * ld + b] = (u - C.ug) * C.RR;
-    o.luu[(int64_t)t * ld + b] = C.RR;
+    o.lu[(int64_t)t * ld + b] = C.lu(u);
+    o.luu[(int64_t)t * ld + b] = C.luu();
 }
 
 // ------------------------------------------------------------ backward pass
@@ -182,8 +186,12 @@ __global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP C, int T, i
 // sweep does not reach are zero (np.zeros_like at ilqr_core.py:118-119).
 // TRUST_NEXT: take sin/cos of next_theta from xs[t+1] (valid when xs is a rollout
 // of us through cartpole_f) instead of re-evaluating them.
-template <bool TRUST_NEXT>
-__device__ __forceinline__ int backward_sweep(const CartpoleC& P, const QRCostP& C, const QPOptsP& QO,
+// RECORD: also write the per-step boxQP result codes and free masks.
+// (Both are compile-time switches so that every loop iteration issues the same
+// memory operations: the wait-count bookkeeping then lets the loads of step i-1
+// stay in flight while step i computes instead of draining the queue.)
+template <bool TRUST_NEXT, bool RECORD, class Cost>
+__device__ __forceinline__ int backward_sweep(const CartpoleC& P, const Cost& C, const QPOptsP& QO,
                                               const BoundsP& bd, int T, int64_t ld, int64_t b,
                                               const double* __restrict__ xs,
                                               const double* __restrict__ us, double mu,
@@ -199,64 +207,87 @@ __device__ __forceinline__ int backward_sweep(const CartpoleC& P, const QRCostP&
     load5(xs, ld, (int64_t)(T - 1) * NX, b, x);
     u = us[(int64_t)(T - 1) * ld + b];
     int rc = BW_OK;
-    int i = T - 1;
-    for (; i >= 0; --i) {
-        // prefetch the operands of step i-1 while step i computes
-        double xp[NX], up = 0.0;
-        if (i > 0) {
-            load5(xs, ld, (int64_t)(i - 1) * NX, b, xp);
-            up = us[(int64_t)(i - 1) * ld + b];
-        } else {
+    // Every lane walks all T steps and stores every step: a lane whose sweep has
+    // ended (non-PD or non-finite Q_uu) stores the zeros the reference leaves in
+    // the steps it never reaches (np.zeros_like, ilqr_core.py:118-119).  Keeping the
+    // trip count and the memory operations the same for every lane lets the loads
+    // of step i-1 stay in flight behind the stores of step i.
+    // results of the previous step, stored one step late (see keep_alive)
+    double pend_k = 0.0, pend_K[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int pend_q = -100, pend_f = 0;
+    for (int i = T - 1; i >= 0; --i) {
+        // prefetch the operands of step i-1 while step i computes (step 0 re-reads itself)
+        double xp[NX], up;
+        int ip = i > 0 ? i - 1 : 0;
+        load5(xs, ld, (int64_t)ip * NX, b, xp);
+        up = us[(int64_t)ip * ld + b];
+        {   // store step i+1 (at i = T-1 nothing is pending: zeros go to slot T-1 and are
+            // overwritten, in program order, by the real step T-1 one iteration later)
+            int is = i + 1 < T ? i + 1 : T - 1;
+            k[(int64_t)is * ld + b] = pend_k;
+            store5(K, ld, (int64_t)is * NX, b, pend_K);
+            if (RECORD) {
+                qp_result_bm[(int64_t)is * ld + b] = pend_q;
+                free_bm[(int64_t)is * ld + b] = pend_f;
+            }
+        }
+        double kk = 0.0, Kr[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        int qres = -100;
+        bool qfree = false;
+        if (rc == BW_OK) {
+            double sn, cn;
+            if (TRUST_NEXT) {
+                sn = xnext[2];
+                cn = xnext[3];
+            } else {
+                double th = det_atan2(x[2], x[3]);
+                det_sincos(th + x[4] * P.dt, sn, cn);
+            }
+            CartpoleJac J;
+            cartpole_jac(P, x, u, sn, cn, J);
+            double kt, Kt[NX];
+            int qr;
+            bool qf;
+            int r = bw_step(C, QO, J, P.dt, x, u, mu, bd.lo, bd.hi, S, kt, Kt, qr, qf);
+            if (r == BW_OK) {
+                kk = kt;
 #pragma unroll
-            for (int a = 0; a < NX; ++a)
-                xp[a] = 0.0;
+                for (int a = 0; a < NX; ++a)
+                    Kr[a] = Kt[a];
+                qres = qr;
+                qfree = qf;
+            } else {
+                rc = r;
+                if (r == BW_NOT_PD)
+                    stopped_at = i;
+            }
         }
-        double sn, cn;
-        if (TRUST_NEXT) {
-            sn = xnext[2];
-            cn = xnext[3];
-        } else {
-            double th = det_atan2(x[2], x[3]);
-            det_sincos(th + x[4] * P.dt, sn, cn);
-        }
-        CartpoleJac J;
-        cartpole_jac(P, x, u, sn, cn, J);
-        double kk, Kr[NX];
-        int qres;
-        bool qfree;
-        rc = bw_step(C, QO, J, P.dt, x, u, mu, bd.lo, bd.hi, S, kk, Kr, qres, qfree);
-        if (rc != BW_OK)
-            break;
-        k[(int64_t)i * ld + b] = kk;
-        store5(K, ld, (int64_t)i * NX, b, Kr);
-        if (qp_result_bm)
-            qp_result_bm[(int64_t)i * ld + b] = qres;
-        if (free_bm)
-            free_bm[(int64_t)i * ld + b] = qfree ? 1 : 0;
+        keep_alive(pend_k);
+#pragma unroll
+        for (int a = 0; a < NX; ++a)
+            keep_alive(pend_K[a]);
+        pend_k = kk;
+        pend_q = qres;
+        pend_f = qfree ? 1 : 0;
 #pragma unroll
         for (int a = 0; a < NX; ++a) {
+            pend_K[a] = Kr[a];
             xnext[a] = x[a];
             x[a] = xp[a];
         }
         u = up;
     }
-    if (rc != BW_OK) {
-        if (rc == BW_NOT_PD)
-            stopped_at = i;
-        for (int j = i; j >= 0; --j) { // the steps the reference never reaches keep zeros
-            k[(int64_t)j * ld + b] = 0.0;
-            for (int a = 0; a < NX; ++a)
-                K[((int64_t)j * NX + a) * ld + b] = 0.0;
-            if (qp_result_bm)
-                qp_result_bm[(int64_t)j * ld + b] = -100;
-            if (free_bm)
-                free_bm[(int64_t)j * ld + b] = 0;
-        }
+    k[b] = pend_k;
+    store5(K, ld, 0, b, pend_K);
+    if (RECORD) {
+        qp_result_bm[b] = pend_q;
+        free_bm[b] = pend_f;
     }
     return rc;
 }
 
-__global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP C, QPOptsP QO, BoundsP bd,
+template <class Cost, bool RECORD>
+__global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP Cp, QPOptsP QOp, BoundsP bd,
                                                    int T, int64_t B, int64_t ld,
                                                    const double* __restrict__ xs,
                                                    const double* __restrict__ us,
@@ -269,9 +300,11 @@ __global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP C, QPOp
     if (b >= B)
         return;
     CartpoleC P = cartpole_consts(mp);
+    Cost C(Cp);
+    QPOptsP QO = qp_opts_in_vgprs(QOp);
     BwAcc S;
     int stopped_at;
-    int rc = backward_sweep<false>(P, C, QO, bd, T, ld, b, xs, us, mu[b], k, K, S, stopped_at,
+    int rc = backward_sweep<false, RECORD>(P, C, QO, bd, T, ld, b, xs, us, mu[b], k, K, S, stopped_at,
                                    qp_result_bm, free_bm);
     dJ[b] = S.dJ1;
     dJ[ld + b] = S.dJ2;
@@ -286,7 +319,8 @@ __global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP C, QPOp
 
 // _forward_pass + _trajectory_cost for one (problem, alpha)   (ilqr_core.py:85-107, :230-239).
 // xs_new / us_new may be null (cost only).
-__device__ __forceinline__ double forward_rollout(const CartpoleC& P, const QRCostP& C, int T,
+template <bool STORE, class Cost>
+__device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost& C, int T,
                                                   int64_t ld, int64_t b,
                                                   const double* __restrict__ xs,
                                                   const double* __restrict__ us,
@@ -302,30 +336,37 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const QRCo
     load5(xs, ld, 0, b, xo);
     load5(K, ld, 0, b, Kr);
     double u = us[b], kk = k[b];
-    for (int t = 0; t < T; ++t) {
-        // prefetch step t+1
-        double xo_p[NX], Kr_p[NX], u_p = 0.0, kk_p = 0.0;
-        if (t + 1 < T) {
-            load5(xs, ld, (int64_t)(t + 1) * NX, b, xo_p);
-            load5(K, ld, (int64_t)(t + 1) * NX, b, Kr_p);
-            u_p = us[(int64_t)(t + 1) * ld + b];
-            kk_p = k[(int64_t)(t + 1) * ld + b];
-        } else {
+    // (x_t, u_t) of the previous step, stored one step late (see keep_alive)
+    double pend_x[NX], pend_u = 0.0;
 #pragma unroll
-            for (int a = 0; a < NX; ++a) {
-                xo_p[a] = 0.0;
-                Kr_p[a] = 0.0;
-            }
+    for (int a = 0; a < NX; ++a)
+        pend_x[a] = xn[a];
+    for (int t = 0; t < T; ++t) {
+        // prefetch step t+1 (the last step re-reads itself)
+        double xo_p[NX], Kr_p[NX], u_p, kk_p;
+        int tp = t + 1 < T ? t + 1 : t;
+        load5(xs, ld, (int64_t)tp * NX, b, xo_p);
+        load5(K, ld, (int64_t)tp * NX, b, Kr_p);
+        u_p = us[(int64_t)tp * ld + b];
+        kk_p = k[(int64_t)tp * ld + b];
+        if (STORE) { // step t-1 (at t = 0: x_0 and a placeholder u_0, rewritten at t = 1)
+            int ts = t > 0 ? t - 1 : 0;
+            store5(xs_new, ld, (int64_t)ts * NX, b, pend_x);
+            us_new[(int64_t)ts * ld + b] = pend_u;
         }
         double un = fw_control(xn, xo, u, kk, Kr, alpha);
-        J = J + qr_l(C, xn, un);
-        if (xs_new) {
-            store5(xs_new, ld, (int64_t)t * NX, b, xn);
-            us_new[(int64_t)t * ld + b] = un;
-        }
+        J = J + C.l(xn, un);
         cartpole_f(P, xn, un, xt);
+        if (STORE) {
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+                keep_alive(pend_x[a]);
+            keep_alive(pend_u);
+        }
+        pend_u = un;
 #pragma unroll
         for (int a = 0; a < NX; ++a) {
+            pend_x[a] = xn[a];
             xn[a] = xt[a];
             xo[a] = xo_p[a];
             Kr[a] = Kr_p[a];
@@ -333,9 +374,12 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const QRCo
         u = u_p;
         kk = kk_p;
     }
-    if (xs_new)
+    if (STORE) {
+        store5(xs_new, ld, (int64_t)(T - 1) * NX, b, pend_x);
+        us_new[(int64_t)(T - 1) * ld + b] = pend_u;
         store5(xs_new, ld, (int64_t)T * NX, b, xn);
-    return J + qr_l_terminal(C, xn);
+    }
+    return J + C.l_terminal(xn);
 }
 
 struct AlphasP {
@@ -343,7 +387,8 @@ struct AlphasP {
 };
 
 // Lanes = problems, blockIdx.y = alpha: every (problem, alpha) pair in parallel.
-__global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP C, AlphasP al, int T,
+template <class Cost, bool STORE>
+__global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP Cp, AlphasP al, int T,
                                                      int64_t B, int64_t ld,
                                                      const double* __restrict__ xs,
                                                      const double* __restrict__ us,
@@ -358,9 +403,10 @@ __global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP C, Al
     if (b >= B)
         return;
     CartpoleC P = cartpole_consts(mp);
+    Cost C(Cp);
     double* xo = xs_new ? xs_new + (int64_t)ai * (T + 1) * NX * ld : nullptr;
     double* uo = us_new ? us_new + (int64_t)ai * T * ld : nullptr;
-    Jnew[(int64_t)ai * ld + b] = forward_rollout(P, C, T, ld, b, xs, us, k, K, al.a[ai], xo, uo);
+    Jnew[(int64_t)ai * ld + b] = forward_rollout<STORE>(P, C, T, ld, b, xs, us, k, K, al.a[ai], xo, uo);
 }
 
 // ------------------------------------------------------------- whole solve
@@ -376,7 +422,8 @@ struct SolveBuffers {       // batch-minor workspace, two copies of everything t
 
 // iLQR.update_u (ilqr_core.py:241-399): every lane runs its own problem to
 // termination; no host involvement per iteration.
-__global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP C, SolveOptsP O, BoundsP bd, int T,
+template <class Cost>
+__global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP Cp, SolveOptsP O, BoundsP bd, int T,
                                                 int64_t B, int64_t ld, SolveBuffers W,
                                                 double* __restrict__ delta_io,
                                                 double* __restrict__ J_out, double* __restrict__ mu_out,
@@ -387,6 +434,8 @@ __global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP C, SolveOp
     if (b >= B)
         return;
     CartpoleC P = cartpole_consts(mp);
+    Cost C(Cp);
+    QPOptsP QO = qp_opts_in_vgprs(O.qp);
     int cur = 0;  // trajectory copy in use
     int gcur = 0; // gain copy in use (holds the solver's k_/K_ on entry)
     double mu = 1.0; // reset per call (:264); delta_ persists (:62)
@@ -402,14 +451,14 @@ __global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP C, SolveOp
             double u = W.us[0][(int64_t)t * ld + b];
             if (t > 0)
                 store5(W.xs[0], ld, (int64_t)t * NX, b, x);
-            J = J + qr_l(C, x, u);
+            J = J + C.l(x, u);
             cartpole_f(P, x, u, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i)
                 x[i] = xn[i];
         }
         store5(W.xs[0], ld, (int64_t)T * NX, b, x);
-        J = J + qr_l_terminal(C, x);
+        J = J + C.l_terminal(x);
     }
 
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
@@ -425,7 +474,7 @@ __global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP C, SolveOp
         bool done = false;
         while (!done) {
             int gnew = gcur ^ 1;
-            int rc = backward_sweep<true>(P, C, O.qp, bd, T, ld, b, xs, us, mu, W.k[gnew], W.K[gnew], S,
+            int rc = backward_sweep<true, false>(P, C, QO, bd, T, ld, b, xs, us, mu, W.k[gnew], W.K[gnew], S,
                                           stopped_at, nullptr, nullptr);
             if (rc != BW_LINALG) {
                 gcur = gnew;
@@ -446,7 +495,7 @@ __global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP C, SolveOp
         int nxt = cur ^ 1;
         for (j = 0; j < O.n_alpha; ++j) {
             double alpha = O.alphas[j];
-            Jnew = forward_rollout(P, C, T, ld, b, xs, us, W.k[gcur], W.K[gcur], alpha, W.xs[nxt],
+            Jnew = forward_rollout<true>(P, C, T, ld, b, xs, us, W.k[gcur], W.K[gcur], alpha, W.xs[nxt],
                                    W.us[nxt]);
             double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
             if (expected <= 0.0) {
@@ -837,6 +886,25 @@ void fill_model(const ilqr_model* m, CartpoleP& mp, QRCostP& C, BoundsP& bd)
     bd.hi = m->upper[0];
 }
 
+bool cost_is_diagonal(const QRCostP& C)
+{
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b)
+            if (a != b && (C.Q[a * 5 + b] != 0.0 || C.Qt[a * 5 + b] != 0.0))
+                return false;
+    return true;
+}
+
+// ILQR_FORCE_DENSE_COST=1 routes diagonal costs through the dense evaluator too
+// (used by the tests to show that both give the same bits).
+bool use_diag(const QRCostP& C)
+{
+    const char* e = std::getenv("ILQR_FORCE_DENSE_COST");
+    if (e && e[0] == '1')
+        return false;
+    return cost_is_diagonal(C);
+}
+
 int fill_qp(const ilqr_opts* o, QPOptsP& q)
 {
     if (!o || o->qp_max_iter < 0 || !(o->qp_step_dec > 0.0) || !(o->qp_step_dec < 1.0) ||
@@ -930,8 +998,12 @@ int ilqr_rollout_cost_bm(const ilqr_model* model, int64_t B, int64_t ld, const d
     QRCostP C;
     BoundsP bd;
     fill_model(model, mp, C, bd);
-    hipLaunchKernelGGL(k_rollout_cost, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
-                       as_stream(stream), mp, C, model->T, B, ld, x0, us, xs, J);
+    if (use_diag(C))
+        hipLaunchKernelGGL(k_rollout_cost<DiagQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
+                           as_stream(stream), mp, C, model->T, B, ld, x0, us, xs, J);
+    else
+        hipLaunchKernelGGL(k_rollout_cost<DenseQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
+                           as_stream(stream), mp, C, model->T, B, ld, x0, us, xs, J);
     return hip_status(hipGetLastError());
 }
 
@@ -973,9 +1045,22 @@ int ilqr_backward_bm(const ilqr_model* model, const ilqr_opts* opts, int64_t B, 
     rc = fill_qp(opts, q);
     if (rc != ILQR_OK)
         return rc;
-    hipLaunchKernelGGL(k_backward, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
-                       as_stream(stream), mp, C, q, bd, model->T, B, ld, xs, us, mu, k, K, dJ, info,
-                       qp_result_bm, free_bm);
+    if ((qp_result_bm == nullptr) != (free_bm == nullptr))
+        return ILQR_ERR_ARG;
+    dim3 grid((unsigned)((B + WAVE - 1) / WAVE));
+    bool rec = qp_result_bm != nullptr, diag = use_diag(C);
+#define ILQR_LAUNCH_BW(COST, REC)                                                                            \
+    hipLaunchKernelGGL((k_backward<COST, REC>), grid, dim3(WAVE), 0, as_stream(stream), mp, C, q, bd, model->T, \
+                       B, ld, xs, us, mu, k, K, dJ, info, qp_result_bm, free_bm)
+    if (diag && rec)
+        ILQR_LAUNCH_BW(DiagQR, true);
+    else if (diag)
+        ILQR_LAUNCH_BW(DiagQR, false);
+    else if (rec)
+        ILQR_LAUNCH_BW(DenseQR, true);
+    else
+        ILQR_LAUNCH_BW(DenseQR, false);
+#undef ILQR_LAUNCH_BW
     return hip_status(hipGetLastError());
 }
 
@@ -996,9 +1081,20 @@ int ilqr_forward_ls_bm(const ilqr_model* model, int64_t B, int64_t ld, int32_t n
     AlphasP al;
     for (int i = 0; i < 32; ++i)
         al.a[i] = i < n_alpha ? alphas[i] : 0.0;
-    hipLaunchKernelGGL(k_forward_ls, dim3((unsigned)((B + WAVE - 1) / WAVE), (unsigned)n_alpha), dim3(WAVE),
-                       0, as_stream(stream), mp, C, al, model->T, B, ld, xs, us, k, K, J_new, xs_new,
-                       us_new);
+    dim3 grid((unsigned)((B + WAVE - 1) / WAVE), (unsigned)n_alpha);
+    bool st = xs_new != nullptr, diag = use_diag(C);
+#define ILQR_LAUNCH_FW(COST, ST)                                                                              \
+    hipLaunchKernelGGL((k_forward_ls<COST, ST>), grid, dim3(WAVE), 0, as_stream(stream), mp, C, al, model->T, B, \
+                       ld, xs, us, k, K, J_new, xs_new, us_new)
+    if (diag && st)
+        ILQR_LAUNCH_FW(DiagQR, true);
+    else if (diag)
+        ILQR_LAUNCH_FW(DiagQR, false);
+    else if (st)
+        ILQR_LAUNCH_FW(DenseQR, true);
+    else
+        ILQR_LAUNCH_FW(DenseQR, false);
+#undef ILQR_LAUNCH_FW
     return hip_status(hipGetLastError());
 }
 
@@ -1054,8 +1150,12 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
-    hipLaunchKernelGGL(k_solve, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, mp, C, O, bd,
-                       (int)T, B, ld, W, delta, J, mu, iters, status, tr);
+    if (use_diag(C))
+        hipLaunchKernelGGL(k_solve<DiagQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, mp, C, O,
+                           bd, (int)T, B, ld, W, delta, J, mu, iters, status, tr);
+    else
+        hipLaunchKernelGGL(k_solve<DenseQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, mp, C, O,
+                           bd, (int)T, B, ld, W, delta, J, mu, iters, status, tr);
     hipLaunchKernelGGL(k_unpack, tile_grid(B, (T + 1) * 5), dim3(256), 0, st, (const double*)W.xs[0],
                        (const double*)W.xs[1], (const int32_t*)W.sel_traj, xs, B, (T + 1) * 5, ld);
     hipLaunchKernelGGL(k_unpack, tile_grid(B, T), dim3(256), 0, st, (const double*)W.us[0],

@@ -42,11 +42,7 @@ __device__ __forceinline__ void det_sincos(double x, double& sn, double& cs)
 {
     const double PIO2_1 = 1.57079632673412561417e+00, PIO2_2 = 6.07710050630396597660e-11,
                  PIO2_2T = 2.02226624879595063154e-21, INVPIO2 = 6.36619772367581382433e-01;
-    if (!(fabs(x) <= 1073741824.0)) {
-        sn = __builtin_nan("");
-        cs = __builtin_nan("");
-        return;
-    }
+    bool bad = !(fabs(x) <= 1073741824.0); // also inf / nan
     double q = rint(x * INVPIO2);
     double t = x - q * PIO2_1;
     double w = q * PIO2_2;
@@ -57,19 +53,16 @@ __device__ __forceinline__ void det_sincos(double x, double& sn, double& cs)
     double s = ksin(y0, y1);
     double c = kcos(y0, y1);
     double quad = q - 4.0 * floor(q * 0.25);
-    if (quad == 0.0) {
-        sn = s;
-        cs = c;
-    } else if (quad == 1.0) {
-        sn = c;
-        cs = -s;
-    } else if (quad == 2.0) {
-        sn = -s;
-        cs = -c;
-    } else {
-        sn = -c;
-        cs = s;
-    }
+    // quadrant selection as selects (no divergent control flow)
+    bool swap = (quad == 1.0) || (quad == 3.0);
+    bool neg_s = (quad == 2.0) || (quad == 3.0);
+    bool neg_c = (quad == 1.0) || (quad == 2.0);
+    double ss = swap ? c : s;
+    double cc = swap ? s : c;
+    ss = neg_s ? -ss : ss;
+    cc = neg_c ? -cc : cc;
+    sn = bad ? __builtin_nan("") : ss;
+    cs = bad ? __builtin_nan("") : cc;
 }
 
 __device__ __forceinline__ double det_atan_pos(double x)
@@ -80,62 +73,57 @@ __device__ __forceinline__ double det_atan_pos(double x)
                  aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
                  aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
                  aT10 = 1.62858201153657823623e-02;
-    double hi, lo, t;
-    bool direct = false;
-    if (x < 0.4375) {
-        direct = true;
-        t = x;
-        hi = 0.0;
-        lo = 0.0;
-    } else if (x < 0.6875) {
-        t = (2.0 * x - 1.0) / (2.0 + x);
+    /* Range selection without branches: t = num / den with (num, den, hi, lo)
+     * picked by interval; the first interval uses den = 1 (x / 1 is exact) and
+     * hi = lo = 0, for which the general formula below reduces to t - t*(s1+s2). */
+    double num = x, den = 1.0, hi = 0.0, lo = 0.0;
+    if (x >= 0.4375) {
+        num = 2.0 * x - 1.0;
+        den = 2.0 + x;
         hi = 4.63647609000806093515e-01;
         lo = 2.26987774529616870924e-17;
-    } else if (x < 1.1875) {
-        t = (x - 1.0) / (x + 1.0);
+    }
+    if (x >= 0.6875) {
+        num = x - 1.0;
+        den = x + 1.0;
         hi = 7.85398163397448278999e-01;
         lo = 3.06161699786838301793e-17;
-    } else if (x < 2.4375) {
-        t = (x - 1.5) / (1.0 + 1.5 * x);
+    }
+    if (x >= 1.1875) {
+        num = x - 1.5;
+        den = 1.0 + 1.5 * x;
         hi = 9.82793723247329054082e-01;
         lo = 1.39033110312309984516e-17;
-    } else {
-        t = -1.0 / x;
+    }
+    if (x >= 2.4375) {
+        num = -1.0;
+        den = x;
         hi = 1.57079632679489655800e+00;
         lo = 6.12323399573676603587e-17;
     }
+    double t = num / den;
     double z = t * t;
     double w = z * z;
     double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (direct)
-        return t - t * (s1 + s2);
     return hi - ((t * (s1 + s2) - lo) - t);
 }
 
 __device__ __forceinline__ double det_atan2(double y, double x)
 {
     const double PI = 3.1415926535897931160e+00, PI_LO = 1.2246467991473531772e-16;
-    if (x != x || y != y)
-        return __builtin_nan("");
     bool xneg = __builtin_signbit(x) != 0;
     bool yneg = __builtin_signbit(y) != 0;
     double ax = fabs(x), ay = fabs(y);
-    if (ay == 0.0) {
-        if (!xneg)
-            return y;
-        return yneg ? -PI : PI;
-    }
-    if (ax == 0.0)
-        return yneg ? -0.5 * PI : 0.5 * PI;
-    double z;
-    if (__builtin_isinf(ax) && __builtin_isinf(ay))
-        z = 0.25 * PI;
-    else
-        z = det_atan_pos(ay / ax);
-    if (!xneg)
-        return yneg ? -z : z;
-    return yneg ? (z - PI_LO) - PI : PI - (z - PI_LO);
+    // general case first, special cases override it (selects, no divergent branches)
+    double z = det_atan_pos(ay / ax);
+    z = (__builtin_isinf(ax) && __builtin_isinf(ay)) ? 0.25 * PI : z;
+    double zl = z - PI_LO;
+    double res = xneg ? (yneg ? zl - PI : PI - zl) : (yneg ? -z : z);
+    res = (ax == 0.0) ? (yneg ? -0.5 * PI : 0.5 * PI) : res;
+    res = (ay == 0.0) ? (xneg ? (yneg ? -PI : PI) : y) : res; // on the x axis: +-0 or +-pi
+    res = (x != x || y != y) ? __builtin_nan("") : res;
+    return res;
 }
 
 } // namespace ilqr

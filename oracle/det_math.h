@@ -98,36 +98,39 @@ static inline double dm_atan_pos(double x)
                  aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
                  aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
                  aT10 = 1.62858201153657823623e-02;
-    double hi, lo, t;
-    int direct = 0;
-    if (x < 0.4375) {
-        direct = 1;
-        t = x;
-        hi = 0.0;
-        lo = 0.0;
-    } else if (x < 0.6875) {
-        t = (2.0 * x - 1.0) / (2.0 + x);
+    /* Range selection without branches: t = num / den with (num, den, hi, lo)
+     * picked by interval; the first interval uses den = 1 (x / 1 is exact) and
+     * hi = lo = 0, for which the general formula below reduces to t - t*(s1+s2). */
+    double num = x, den = 1.0, hi = 0.0, lo = 0.0;
+    if (x >= 0.4375) {
+        num = 2.0 * x - 1.0;
+        den = 2.0 + x;
         hi = 4.63647609000806093515e-01;
         lo = 2.26987774529616870924e-17;
-    } else if (x < 1.1875) {
-        t = (x - 1.0) / (x + 1.0);
+    }
+    if (x >= 0.6875) {
+        num = x - 1.0;
+        den = x + 1.0;
         hi = 7.85398163397448278999e-01;
         lo = 3.06161699786838301793e-17;
-    } else if (x < 2.4375) {
-        t = (x - 1.5) / (1.0 + 1.5 * x);
+    }
+    if (x >= 1.1875) {
+        num = x - 1.5;
+        den = 1.0 + 1.5 * x;
         hi = 9.82793723247329054082e-01;
         lo = 1.39033110312309984516e-17;
-    } else {
-        t = -1.0 / x;
+    }
+    if (x >= 2.4375) {
+        num = -1.0;
+        den = x;
         hi = 1.57079632679489655800e+00;
         lo = 6.12323399573676603587e-17;
     }
+    double t = num / den;
     double z = t * t;
     double w = z * z;
     double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (direct)
-        return t - t * (s1 + s2);
     return hi - ((t * (s1 + s2) - lo) - t);
 }
 

@@ -328,3 +328,26 @@ def test_boxqp1_on_captured_backward_pass_inputs(hip):
     assert np.array_equal(cnt[:, 0], ref["n_iter"]) and np.array_equal(cnt[:, 1], ref["n_factor"])
     assert np.array_equal(cnt[:, 2], ref["n_backtrack"])
     assert eq(out["Hff"].cpu().numpy()[:, 0, 0], ref["Hff"][:, 0, 0])
+
+
+def test_dense_and_diagonal_cost_evaluators_agree(hip, monkeypatch):
+    """A diagonal Q takes the evaluator that skips the zero products; forcing the
+    dense one must give the same bits, and a full Q must match the oracle."""
+    B, T = 130, 60
+    Mo = co.cartpole_model(T=T)
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=41, seed_u=42)
+    M = hip_model(hip, Mo)
+    a = hip.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0))
+    monkeypatch.setenv("ILQR_FORCE_DENSE_COST", "1")
+    b = hip.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0))
+    monkeypatch.delenv("ILQR_FORCE_DENSE_COST")
+    for key in ("xs", "us", "J", "k", "K", "mu", "delta"):
+        assert eq(a[key].cpu().numpy(), b[key].cpu().numpy()), key
+    assert np.array_equal(a["iters"].cpu().numpy(), b["iters"].cpu().numpy())
+    # a full (non-diagonal, non-symmetric) Q and Q_terminal
+    r = np.random.RandomState(4)
+    Qf = Mo.Q + r.uniform(-2, 2, (5, 5))
+    Qtf = Mo.Qt + r.uniform(-2, 2, (5, 5))
+    Mf = co.Model(co.MODEL_CARTPOLE, 5, 1, T, co.COST_QR, co.MATH_DET, True, Q=Qf, R=Mo.R, Q_terminal=Qtf,
+                  x_goal=Mo.x_goal, u_goal=[0.3], lower=Mo.lower, upper=Mo.upper)
+    _check_solve(hip, Mf, x0, us0, 30)
