@@ -39,7 +39,7 @@ class OptsC(C.Structure):
         ("mu_min", C.c_double), ("mu_max", C.c_double), ("delta0", C.c_double),
         ("qp_max_iter", C.c_int32), ("pad_", C.c_int32),
         ("qp_min_grad", C.c_double), ("qp_min_rel_improve", C.c_double), ("qp_step_dec", C.c_double),
-        ("qp_min_step", C.c_double), ("qp_armijo", C.c_double),
+        ("qp_min_step", C.c_double), ("qp_armijo", C.c_double), ("mu_init", C.c_double),
     ]
 
 
@@ -119,7 +119,7 @@ class Model:
 class Opts:
     def __init__(self, max_iter=200, tol=1e-4, line_search_steps=30, scale=0.1, mu_min=1e-6, mu_max=1e10,
                  delta0=2.0, qp_max_iter=100, qp_min_grad=1e-8, qp_min_rel_improve=1e-8, qp_step_dec=0.9,
-                 qp_min_step=1e-22, qp_armijo=0.1, alphas=None):
+                 qp_min_step=1e-22, qp_armijo=0.1, alphas=None, mu_from_array=False):
         # the reference's schedule, ilqr_core.py:267
         self.alphas = _host(1.1 ** (-np.arange(line_search_steps) ** 2) if alphas is None else alphas, (-1,))
         o = OptsC()
@@ -130,6 +130,7 @@ class Opts:
         o.qp_max_iter = qp_max_iter
         o.qp_min_grad, o.qp_min_rel_improve, o.qp_step_dec = qp_min_grad, qp_min_rel_improve, qp_step_dec
         o.qp_min_step, o.qp_armijo = qp_min_step, qp_armijo
+        o.mu_init = 0.0 if mu_from_array else -1.0
         self.c = o
         self.max_iter = int(max_iter)
 
@@ -238,7 +239,7 @@ TRACE_FIELDS = (("J", "f8"), ("accepted", "i4"), ("alpha_idx", "i4"), ("mu", "f8
                 ("qp_iter", "i4"), ("qp_backtrack", "i4"), ("n_clamped", "i4"), ("stopped_at", "i4"))
 
 
-def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, out=None):
+def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, out=None, mu=None):
     """ilqr_solve_batched on ref-layout tensors.  Returns a dict of device tensors.
 
     ``out`` may carry preallocated result tensors (keys xs, us, J, mu, iters,
@@ -261,9 +262,11 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
         res["xs"] = torch.empty((B, T + 1, n), dtype=torch.float64, device=dev)
         res["us"] = torch.empty((B, T, m), dtype=torch.float64, device=dev)
         res["J"] = torch.empty(B, dtype=torch.float64, device=dev)
-        res["mu"] = torch.empty(B, dtype=torch.float64, device=dev)
+        res["mu"] = torch.ones(B, dtype=torch.float64, device=dev) if mu is None else mu
         res["iters"] = torch.empty(B, dtype=torch.int32, device=dev)
         res["status"] = torch.empty(B, dtype=torch.int32, device=dev)
+    if mu is not None:
+        res["mu"] = mu
     need = solve_workspace_bytes(M, B)
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -75,6 +75,7 @@ __device__ __forceinline__ QPOptsP qp_opts_in_vgprs(const QPOptsP& o)
 
 struct SolveOptsP {
     int max_iter, n_alpha;
+    int mu_from_array; // 0: mu starts at 1.0 (ilqr_core.py:264); 1: at mu_out[b]
     double tol, scale, mu_min, mu_max, delta0;
     double alphas[32];
     QPOptsP qp;
@@ -329,9 +330,15 @@ struct DiagQR {
 
 __device__ __forceinline__ double clamp1(double lo, double hi, double v)
 {
-    // np.maximum(lower, np.minimum(upper, x)), NaN propagating (ilqr_boxQP.py:37)
-    double t = (v != v) ? v : (hi < v ? hi : v);
-    return (t != t) ? t : (lo > t ? lo : t);
+    // np.maximum(lower, np.minimum(upper, x)), NaN propagating (ilqr_boxQP.py:37).
+    // fmin/fmax return the other operand when one is NaN, so NaNs (never seen on a
+    // healthy trajectory) are put back by hand behind a wave-uniform branch.
+    double r = fmax(lo, fmin(hi, v));
+    if (__ballot((v != v) | (lo != lo) | (hi != hi)) != 0ull) {
+        double t = (v != v) ? v : (hi < v ? hi : v);
+        r = (t != t) ? t : (lo > t ? lo : t);
+    }
+    return r;
 }
 
 __device__ __forceinline__ double qp_value1(double H, double g, double x)
@@ -375,8 +382,10 @@ struct QP1Out {
 // boxQP for one scalar unknown (ilqr_boxQP.py:9-186) with x0 given.  Every branch
 // of the reference is kept, including the first pass that runs with the
 // un-factorised H_ff = ones (:36, :108-117).
-__device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double g, double lo, double hi,
-                                       double x0, QP1Out& out)
+// sqrtH, rsqrtH: sqrt(H) and 1.0 / sqrt(H) as the caller already has them from
+// its own Cholesky of the same 1x1 matrix (same input, same bits).
+__device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double sqrtH, double rsqrtH, double g,
+                                       double lo, double hi, double x0, QP1Out& out)
 {
     bool clamped = false, free_ = false;
     double oldvalue = 0.0;
@@ -409,8 +418,8 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double g, dou
         }
         bool factorize = (iter == 1) || (oldclamped != clamped);
         if (factorize) {
-            hff = sqrt(H);
-            rdiag = 1.0 / hff;
+            hff = sqrtH;
+            rdiag = rsqrtH;
             ++n_factor;
         }
         double gnorm = fabs(grad);
@@ -602,7 +611,7 @@ __device__ __forceinline__ int bw_step(const Cost& C, const QPOptsP& QO, const C
 
     // boxQP(Q_uu, Q_u, lower - u, upper - u, k[i], ...)     (:152-156)
     QP1Out qp;
-    boxqp1(QO, Quu, Qu, lower - u, upper - u, k0, qp);
+    boxqp1(QO, Quu, L, rL, Qu, lower - u, upper - u, k0, qp);
     double kk = qp.x;
     S.qp_iter += qp.n_iter;
     S.qp_backtrack += qp.n_backtrack;

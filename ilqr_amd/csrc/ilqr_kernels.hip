@@ -438,7 +438,7 @@ __global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP Cp, SolveO
     QPOptsP QO = qp_opts_in_vgprs(O.qp);
     int cur = 0;  // trajectory copy in use
     int gcur = 0; // gain copy in use (holds the solver's k_/K_ on entry)
-    double mu = 1.0; // reset per call (:264); delta_ persists (:62)
+    double mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
     double delta = delta_io[b];
 
     // initial rollout and cost (:269-271); us_init is in W.us[0], x0 in rows 0..4 of W.xs[0]
@@ -782,7 +782,8 @@ __global__ __launch_bounds__(256) void k_boxqp1(QPOptsP O, int64_t B, const doub
     QP1Out out;
     double lo = lower[q], hi = upper[q];
     double xs = x0 ? x0[q] : (lo + hi) / 2;
-    boxqp1(O, H[q], g[q], lo, hi, xs, out);
+    double sq = sqrt(H[q]);
+    boxqp1(O, H[q], sq, 1.0 / sq, g[q], lo, hi, xs, out);
     if (!(fabs(H[q]) < __builtin_inf()) && O.max_iter > 0) {
         // non-finite H: the first pass either finds everything clamped (:92) or
         // np.linalg.eigvals raises (:103); boxqp1 is written for the finite H the
@@ -935,6 +936,7 @@ int fill_opts(const ilqr_opts* o, SolveOptsP& s)
         return ILQR_ERR_ARG;
     s.max_iter = o->max_iter;
     s.n_alpha = o->n_alpha;
+    s.mu_from_array = (o->mu_init >= 0.0) ? 1 : 0;
     s.tol = o->tol;
     s.scale = o->scale;
     s.mu_min = o->mu_min;

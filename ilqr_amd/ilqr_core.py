@@ -1,0 +1,257 @@
+"""iLQR solver and receding-horizon driver (mirror of ilqr/ilqr_core.py) on MI355X.
+
+Same constructor, methods, attributes and semantics as the reference classes, with
+one extension: every entry point also takes a BATCH of independent problems
+(``x0 [B, n]``, ``u_seq_init [B, N, m]``) and solves them in one device launch.
+numpy in -> numpy out; torch (ROCm) tensors in -> torch tensors out, no host copy.
+
+The whole ``update_u`` loop runs on the GPU (see ilqr_amd/csrc).  There is no CPU
+fallback: without a GPU or without the built library these classes raise.
+"""
+import abc
+import warnings
+
+import numpy as np
+
+from . import _hip
+from .ilqr_cost import QRCost
+
+
+class BaseTrajOptimizer(abc.ABC):
+    """Base trajectory optimizer (ilqr_core.py:12-28)."""
+
+    @abc.abstractmethod
+    def update_u(self, x0, u_seq_init, *args, **kwargs):
+        """x0 [n], u_seq_init [N, m] -> (xs [N+1, n], us [N, m])."""
+        raise NotImplementedError
+
+
+def _is_torch(a):
+    return type(a).__module__.split(".")[0] == "torch"
+
+
+class iLQR(BaseTrajOptimizer):
+    """Finite Horizon Iterative Linear Quadratic Regulator (ilqr_core.py:30-399)."""
+
+    def __init__(self, sys_dynamics, cost_func, time_steps=15, max_reg=1e10, control_limit=True,
+                 use_second_order=False):
+        self.dynamics = sys_dynamics
+        self.cost = cost_func
+        self.N = int(time_steps)
+        self.control_limit = control_limit
+
+        if getattr(sys_dynamics, "device_model", None) != "cartpole":
+            raise NotImplementedError(
+                "iLQR on the GPU needs a dynamics model with a device implementation "
+                "(ilqr_amd.cartpole.CartPoleDynamics); %r evaluates through Python callbacks, which cannot "
+                "run inside a kernel" % type(sys_dynamics).__name__)
+        if not isinstance(cost_func, QRCost):
+            raise NotImplementedError("only QRCost has a device implementation")
+        if control_limit is not True:
+            # In the reference this branch keeps the positive-sign warm-start gains, predicts a
+            # cost INCREASE and rejects every iteration (ilqr_core.py:145,162,305-308).
+            raise NotImplementedError("control_limit=False is not usable in the reference solver either "
+                                      "(wrong-sign gains); only the control-limited path is implemented")
+        if use_second_order:
+            raise NotImplementedError("second-order (DDP) terms are unreachable in the reference "
+                                      "(ilqr_core.py:52) and are not implemented")
+        self.use_second_order_ = False
+        self.lower_bound = self.dynamics.lower_bound
+        self.upper_bound = self.dynamics.upper_bound
+
+        # regularisation schedule constants (ilqr_core.py:58-62)
+        self.mu_min_ = 1e-6
+        self.mu_max_ = max_reg
+        self.mu_ = 1.0
+        self.delta_0_ = 2.0
+        self.delta_ = self.delta_0_
+
+        n, m = self.dynamics.state_dimension, self.dynamics.control_dimension
+        self.k_ = np.zeros((self.N, m))
+        self.K_ = np.zeros((self.N, m, n))
+        # per-problem results of the last call (device-side bookkeeping the reference does not have)
+        self.iterations_ = None
+        self.status_ = None
+        self.J_ = None
+        self._batch = None
+        super().__init__()
+
+    # ------------------------------------------------------------------ helpers
+    def _model(self):
+        d, c = self.dynamics, self.cost
+        return _hip.Model(self.N, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal, self.lower_bound, self.upper_bound,
+                          dt=d.tau, mc=d.masscart, mp=d.masspole, l=d.length, g=d.gravity)
+
+    def _device(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise _hip.IlqrHipError("no GPU visible: the solve path has no CPU fallback")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def _to_dev(self, a, shape):
+        import torch
+        if _is_torch(a):
+            return a.to(device=self._device(), dtype=torch.float64).reshape(shape).contiguous()
+        return torch.tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape)),
+                            device=self._device())
+
+    def _state_for_batch(self, B):
+        """Solver state carried across calls (delta_, k_, K_): per-problem copies on the device.
+        State left by a single-problem call (or a fresh solver) is broadcast to the batch."""
+        import torch
+        n, m = self.dynamics.state_dimension, self.dynamics.control_dimension
+        dev = self._device()
+
+        def bc(val, shape):
+            t = val if _is_torch(val) else torch.tensor(np.asarray(val, dtype=np.float64))
+            t = t.to(device=dev, dtype=torch.float64)
+            if t.dim() == len(shape):
+                t = t.expand((B,) + tuple(shape))
+            elif t.shape[0] != B:
+                raise ValueError("solver state holds %d problems, this call has %d (use a new iLQR object, "
+                                 "or keep the batch size)" % (t.shape[0], B))
+            return t.contiguous().clone()
+        return bc(self.delta_, ()), bc(self.k_, (self.N, m)), bc(self.K_, (self.N, m, n))
+
+    # ----------------------------------------------------------------- update_u
+    def update_u(self, x0, u_seq_init, n_interations=200, tolerance=1e-4, on_iteration=None,
+                 line_search_steps=30, scale=0.1, n_iterations=None):
+        """Update the optimal control sequence (ilqr_core.py:241-399).
+
+        x0 [n] or [B, n]; u_seq_init [N, m] or [B, N, m].  ``n_interations`` is the
+        reference's (misspelt) keyword; ``n_iterations``, the spelling its own MPC driver
+        passes (ilqr_core.py:457), is accepted as well.
+        on_iteration(iteration, xs, us, J_opt, accepted, converged) is called after every
+        iteration as in the reference; with a batch the arguments are arrays over the
+        problems still running.  It makes the solve run one launch per iteration.
+        Returns (xs [.., N+1, n], us [.., N, m]).
+        """
+        import torch
+        if n_iterations is not None:
+            n_interations = n_iterations
+        n, m, N = self.dynamics.state_dimension, self.dynamics.control_dimension, self.N
+        as_torch = _is_torch(x0) or _is_torch(u_seq_init)
+        x0_nd = x0.dim() if _is_torch(x0) else np.ndim(x0)
+        single = x0_nd == 1
+        u_shape = tuple(u_seq_init.shape)
+        assert u_shape[-2] == N, 'The length of control sequence should {}, yet is {} instead.'.format(N, u_shape[-2])
+        x0_d = self._to_dev(x0, (-1, n))
+        B = x0_d.shape[0]
+        us_d = self._to_dev(u_seq_init, (B, N, m))
+        delta, k, K = self._state_for_batch(B)
+        M = self._model()
+        kw = dict(tol=tolerance, line_search_steps=line_search_steps, scale=scale, mu_min=self.mu_min_,
+                  mu_max=self.mu_max_ if self.mu_max_ else 0.0, delta0=self.delta_0_)
+
+        if on_iteration is None:
+            res = _hip.solve(M, _hip.Opts(max_iter=n_interations, **kw), x0_d, us_d, delta=delta, k=k, K=K)
+            xs, us, J, mu = res["xs"], res["us"], res["J"], res["mu"]
+            iters, status = res["iters"], res["status"]
+        else:
+            xs, us, J, mu, iters, status = self._solve_stepwise(M, kw, n_interations, x0_d, us_d, delta, k, K,
+                                                                on_iteration, single, as_torch)
+        torch.cuda.synchronize()
+
+        def out(t, shape=None):
+            t = t[0] if single else t
+            return t if as_torch else t.cpu().numpy()
+        self.k_, self.K_ = out(k), out(K)
+        self.delta_ = float(delta[0]) if single else out(delta)
+        self.mu_ = float(mu[0]) if single else out(mu)
+        self.nominal_xs_, self.nominal_us_ = out(xs), out(us)
+        self.J_ = float(J[0]) if single else out(J)
+        self.iterations_ = int(iters[0]) if single else out(iters)
+        self.status_ = int(status[0]) if single else out(status)
+        return self.nominal_xs_, self.nominal_us_
+
+    def _solve_stepwise(self, M, kw, max_iter, x0_d, us_d, delta, k, K, on_iteration, single, as_torch):
+        """One launch per iteration so that the callback sees every iterate.  Each launch
+        re-rolls the current controls (same inputs, same bits) and continues from the
+        carried mu/delta/k/K, so the iterates equal those of the single-launch solve."""
+        import torch
+        B = x0_d.shape[0]
+        dev = x0_d.device
+        mu = torch.ones(B, dtype=torch.float64, device=dev)
+        iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        xs = torch.empty((B, self.N + 1, x0_d.shape[1]), dtype=torch.float64, device=dev)
+        us = us_d.clone()
+        J = torch.empty(B, dtype=torch.float64, device=dev)
+        active = torch.ones(B, dtype=torch.bool, device=dev)
+        O = _hip.Opts(max_iter=1, mu_from_array=True, **kw)
+        first = True
+        for it in range(max_iter):
+            idx = torch.nonzero(active).flatten()
+            if idx.numel() == 0:
+                break
+            d_i, k_i, K_i, mu_i = delta[idx].contiguous(), k[idx].contiguous(), K[idx].contiguous(), mu[idx].contiguous()
+            res = _hip.solve(M, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
+                             trace=True)
+            acc = res["trace"]["accepted"][0] == 1
+            conv = res["status"] == _hip.STATUS_CONVERGED
+            stopped = res["status"] == _hip.STATUS_MU_MAX
+            delta[idx], k[idx], K[idx], mu[idx] = d_i, k_i, K_i, mu_i
+            xs[idx], us[idx], J[idx] = res["xs"], res["us"], res["J"]
+            iters[idx] += 1
+            status[idx] = res["status"]
+            # the reference leaves the loop on mu >= mu_max BEFORE the callback (ilqr_core.py:337-345)
+            call = ~stopped
+            if bool(call.any()):
+                sel = idx[call]
+
+                def view(t):
+                    t = t[0] if single else t
+                    return t if as_torch else t.cpu().numpy()
+                if single:
+                    on_iteration(it, view(xs[sel]), view(us[sel]), float(J[sel][0]), bool(acc[call][0]),
+                                 bool(conv[call][0]))
+                else:
+                    on_iteration(it, view(xs[sel]), view(us[sel]), view(J[sel]), view(acc[call]), view(conv[call]))
+            active[idx] = ~(conv | stopped)
+            first = False
+        return xs, us, J, mu, iters, status
+
+
+class RecedingHorizonController(object):
+    """Receding horizon controller for model predictive control (ilqr_core.py:400-466)."""
+
+    def __init__(self, x0, u_seq_init, controller, env=None):
+        self.xs_ = x0
+        self.us_ = u_seq_init
+        self.controller_ = controller
+        self.env = env
+
+    def set_state(self, x):
+        """Set the current state [n] (or [B, n])."""
+        self.xs_ = x
+
+    def control(self, step_size=1, initial_n_iterations=200, subsequent_n_iterations=10, *args, **kwargs):
+        """Generator of (xs[:step_size+1], us[:step_size]) per re-fit (ilqr_core.py:422-466).
+
+        As in the reference the controller's state moves to where the model predicts the
+        system will be after ``step_size`` steps; correct it with set_state() between
+        iterations to close the loop on a real plant.  The reference as shipped raises
+        TypeError here (it passes ``n_iterations=`` to a function whose parameter is spelt
+        ``n_interations``); this is the behaviour that call intends.
+        """
+        n_iterations = initial_n_iterations
+        while True:
+            xs, us = self.controller_.update_u(self.xs_, self.us_, *args, n_iterations=n_iterations, **kwargs)
+            batched = xs.ndim == 3
+            if batched:
+                self.xs_ = xs[:, step_size]
+                yield xs[:, :step_size + 1], us[:, :step_size]
+                us_start, us_end = us[:, step_size:], us[:, -step_size:]
+                axis = 1
+            else:
+                self.xs_ = xs[step_size]
+                yield xs[:step_size + 1], us[:step_size]
+                us_start, us_end = us[step_size:], us[-step_size:]
+                axis = 0
+            # next seed: move along the current path and repeat its tail (ilqr_core.py:463-465)
+            if _is_torch(us):
+                import torch
+                self.us_ = torch.cat([us_start, us_end], dim=axis)
+            else:
+                self.us_ = np.concatenate([us_start, us_end], axis=axis)
+            n_iterations = subsequent_n_iterations

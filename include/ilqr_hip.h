@@ -70,6 +70,11 @@ typedef struct ilqr_opts {
     int32_t qp_max_iter;
     int32_t pad_;
     double qp_min_grad, qp_min_rel_improve, qp_step_dec, qp_min_step, qp_armijo;
+    /* update_u resets the regularisation to 1.0 on entry (:264): pass a negative
+     * value (or NaN) for that.  A value >= 0 starts every problem from mu_init[b]
+     * read from the `mu` output array instead (in/out), which lets a caller run
+     * the loop one iteration per call (on_iteration callbacks, :342-345). */
+    double mu_init;
 } ilqr_opts;
 
 /* Optional per-iteration record of ilqr_solve_batched, each array [max_iter, B]

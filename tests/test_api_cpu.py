@@ -1,0 +1,162 @@
+"""CPU-side tests: host logic of the reference-API mirror, the C ABI surface, and the
+rule that the product path has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ilqr_amd
+from ilqr_amd import _hip
+from ilqr_amd.cartpole import CartPoleDynamics
+from ilqr_amd.ilqr_core import RecedingHorizonController, iLQR
+from ilqr_amd.ilqr_cost import Cost, QRCost
+from ilqr_amd.ilqr_dynamics import Dynamics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ilqr_hip.h")).read()
+    declared = set(re.findall(r"\b(ilqr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ilqr_status"}
+    assert len(declared) >= 14
+    lib = ctypes.CDLL(_hip.LIB_PATH)  # loading needs no GPU
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert set(_hip.EXPORTS) == declared
+    assert lib.ilqr_version() >= 100
+    lib.ilqr_bm_ld.restype = ctypes.c_int64
+    lib.ilqr_bm_ld.argtypes = [ctypes.c_int64]
+    assert lib.ilqr_bm_ld(1) == 64 and lib.ilqr_bm_ld(64) == 64 and lib.ilqr_bm_ld(65) == 128
+    lib.ilqr_status_string.restype = ctypes.c_char_p
+    assert lib.ilqr_status_string(0) == b"ok" and b"argument" in lib.ilqr_status_string(-1)
+
+
+def test_argument_checks_need_no_gpu():
+    """Bad arguments are rejected before any device work."""
+    lib = _hip.lib()
+    M = _hip.Model(10, np.eye(5), np.eye(1), lower=[-1.0], upper=[1.0])
+    assert lib.ilqr_solve_workspace_bytes(ctypes.byref(M.c), 100) == (2 * (11 * 5 + 10 + 10 + 50) * 128 * 8 + 2 * 128 * 4)
+    assert lib.ilqr_rollout_cost_bm(ctypes.byref(M.c), ctypes.c_int64(4), ctypes.c_int64(64), None, None, None, None,
+                                    None) == -1
+    bad = _hip.Model(10, np.eye(5), np.eye(1), lower=[-1.0], upper=[1.0])
+    bad.c.n = 4
+    assert lib.ilqr_rollout_cost_bm(ctypes.byref(bad.c), ctypes.c_int64(4), ctypes.c_int64(64), None, None, None,
+                                    None, None) == -2
+    assert lib.ilqr_solve_workspace_bytes(ctypes.byref(bad.c), 100) == 0
+    assert lib.ilqr_boxqp_batched(ctypes.c_int64(1), ctypes.c_int32(9), *([None] * 13)) == -1
+
+
+def test_reference_import_names():
+    import ilqr
+    from ilqr import iLQR as A
+    from ilqr.cartpole import CartPoleDynamics as B
+    from ilqr.ilqr_cost import QRCost as C_
+    from ilqr.ilqr_boxQP import boxQP  # noqa: F401
+    from ilqr.ilqr_core import RecedingHorizonController as D
+    assert A is iLQR and B is CartPoleDynamics and C_ is QRCost and D is RecedingHorizonController
+    assert ilqr.iLQR is ilqr_amd.iLQR
+
+
+def test_solver_construction_and_attributes():
+    dyn = CartPoleDynamics(0.05)
+    cost = QRCost(100 * np.eye(5), np.array([[5.0]]), Q_terminal=100 * np.eye(5),
+                  x_goal=dyn.augment_state(np.zeros(4)))
+    s = iLQR(dyn, cost, 100)
+    assert (s.N, s.control_limit, s.mu_min_, s.mu_max_, s.mu_, s.delta_0_, s.delta_) == (100, True, 1e-6, 1e10, 1.0,
+                                                                                          2.0, 2.0)
+    assert s.k_.shape == (100, 1) and s.K_.shape == (100, 1, 5) and not s.k_.any() and not s.K_.any()
+    assert np.array_equal(s.lower_bound, [-5.0]) and np.array_equal(s.upper_bound, [5.0])
+    assert iLQR(dyn, cost).N == 15
+    assert isinstance(dyn, Dynamics) and isinstance(cost, Cost)
+    assert (dyn.state_dimension, dyn.control_dimension, dyn.has_hessians) == (5, 1, False)
+    with pytest.raises(NotImplementedError):
+        iLQR(dyn, cost, 10, control_limit=False)
+    with pytest.raises(NotImplementedError):
+        iLQR(dyn, cost, 10, use_second_order=True)
+
+    class Py(Dynamics):
+        state_dimension = control_dimension = 1
+        has_hessians = False
+
+        def f(self, x, u, i):
+            return x
+
+        f_x = f_u = f
+    with pytest.raises(NotImplementedError):
+        iLQR(Py(), cost, 10)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    dyn = CartPoleDynamics(0.05)
+    s = iLQR(dyn, QRCost(np.eye(5), np.eye(1)), 10)
+    with pytest.raises(_hip.IlqrHipError):
+        s.update_u(np.zeros(5), np.zeros((10, 1)))
+    from ilqr_amd.ilqr_boxQP import boxQP
+    with pytest.raises(_hip.IlqrHipError):
+        boxQP(np.eye(2), np.ones(2), -np.ones(2), np.ones(2), np.zeros(2))
+
+
+def test_state_augmentation_round_trip():
+    r = np.random.RandomState(0)
+    st = r.uniform(-3, 3, (20, 4))
+    aug = CartPoleDynamics.augment_state(st)
+    assert aug.shape == (20, 5)
+    np.testing.assert_allclose(aug[:, 2] ** 2 + aug[:, 3] ** 2, 1.0, rtol=1e-15)
+    np.testing.assert_allclose(CartPoleDynamics.reduce_state(aug), st, rtol=1e-14, atol=1e-14)
+    one = CartPoleDynamics.augment_state(np.array([0.0, 0.0, np.pi, 0.0]))
+    assert one.shape == (5,) and one[3] == -1.0
+    assert CartPoleDynamics.reduce_state(one).shape == (4,)
+
+
+def test_qrcost_host_formulas(golden_dir):
+    """Value with the 1/2, gradients without (ilqr_cost.py:547 vs :569)."""
+    r = np.random.RandomState(1)
+    Q, R = r.randn(5, 5), r.randn(1, 1)
+    c = QRCost(Q, R, Q_terminal=2 * Q, x_goal=r.randn(5), u_goal=r.randn(1))
+    x, u = r.randn(5), r.randn(1)
+    xd, ud = x - c.x_goal, u - c.u_goal
+    assert np.isclose(c.l(x, u, 0), 0.5 * xd @ Q @ xd + 0.5 * ud @ R @ ud)
+    assert np.isclose(c.l(x, None, 3, terminal=True), xd @ Q @ xd)
+    np.testing.assert_allclose(c.l_x(x, u, 0), xd @ (Q + Q.T))
+    np.testing.assert_allclose(c.l_u(x, u, 0), ud @ (R + R.T))
+    assert np.array_equal(c.l_xx(x, u, 0), Q + Q.T) and np.array_equal(c.l_xx(x, u, 0, True), 2 * (Q + Q.T))
+    assert c.l_ux(x, u, 0).shape == (1, 5) and not c.l_ux(x, u, 0).any()
+    assert not c.l_uu(x, u, 0, terminal=True).any() and not c.l_u(x, u, 0, terminal=True).any()
+    with pytest.raises(AssertionError):
+        QRCost(np.eye(5), np.eye(1), Q_terminal=np.eye(4))
+
+
+def test_receding_horizon_shift_logic():
+    """The generator's bookkeeping (ilqr_core.py:456-466) with a stub controller."""
+    class Stub:
+        def __init__(self):
+            self.calls = []
+
+        def update_u(self, x, us, n_iterations=None):
+            self.calls.append((np.array(x), np.array(us), n_iterations))
+            T = us.shape[-2]
+            if us.ndim == 3:
+                xs = np.cumsum(np.concatenate([x[:, None, :], np.repeat(us, x.shape[-1], axis=-1)], 1), 1)
+            else:
+                xs = np.cumsum(np.vstack([x[None], np.repeat(us, x.shape[-1], axis=-1)]), 0)
+            assert xs.shape[-2] == T + 1
+            return xs, us + 1.0
+    for batched in (False, True):
+        st = Stub()
+        x0 = np.zeros((3, 2)) if batched else np.zeros(2)
+        us0 = np.arange(5.0).reshape(5, 1) * (np.ones((3, 1, 1)) if batched else 1.0)
+        gen = RecedingHorizonController(x0, us0, st, None).control(step_size=2, initial_n_iterations=7,
+                                                                   subsequent_n_iterations=3)
+        xs, us = next(gen)
+        assert xs.shape[-2] == 3 and us.shape[-2] == 2
+        xs, us = next(gen)
+        assert [c[2] for c in st.calls] == [7, 3]
+        first_us = st.calls[0][1] + 1.0
+        expect = np.concatenate([first_us[..., 2:, :], first_us[..., -2:, :]], axis=-2)
+        assert np.array_equal(st.calls[1][1], expect)
