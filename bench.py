@@ -110,10 +110,8 @@ def main():
     delta = torch.empty(B, dtype=torch.float64, device=dev)
     k = torch.empty((B, T, 1), dtype=torch.float64, device=dev)
     K = torch.empty((B, T, 1, 5), dtype=torch.float64, device=dev)
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = {name: [torch.empty_like(out_buf[name]) for _ in range(world)]
-                    for name in ("J", "iters", "status", "xs", "us")}
+    from ilqr_amd import sharding
+    sizes = [B] * world
 
     def step():
         # a freshly constructed solver per step: delta_ = 2, k_ = K_ = 0 (ilqr_core.py:58-65)
@@ -123,7 +121,7 @@ def main():
         res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws, out=out_buf)
         if world > 1:  # the only exchange of the path: results to rank 0 over xGMI
             for name in ("J", "iters", "status", "xs", "us"):
-                dist.gather(out_buf[name], gathered[name] if rank == 0 else None, dst=0)
+                sharding.gather_to_root(out_buf[name], sizes, dst=0)
         return res
 
     def barrier():
