@@ -57,7 +57,7 @@ EXPORTS = (
     "ilqr_version", "ilqr_status_string", "ilqr_bm_ld", "ilqr_pack_bm", "ilqr_unpack_bm",
     "ilqr_rollout_cost_bm", "ilqr_deriv_bm", "ilqr_backward_bm", "ilqr_forward_ls_bm",
     "ilqr_boxqp_batched", "ilqr_solve_workspace_bytes", "ilqr_solve_batched",
-    "ilqr_cartpole_plant_step", "ilqr_detmath",
+    "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
 )
 
 _lib = None

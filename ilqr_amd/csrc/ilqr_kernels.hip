@@ -47,7 +47,17 @@ __device__ __forceinline__ void store5(double* base, int64_t ld, int64_t row0, i
 
 // ------------------------------------------------------ layout conversion
 
-// ref [B, R] -> bm [R, ld]: 64x64 tile through LDS so both sides are coalesced.
+// Element (row r, problem b) of a batch-minor array.  ld > 0: plain [R, ld].
+// ld == 0: wave-tiled [ceil(B/64), R, 64] -- the 64 problems of one wavefront keep
+// all their rows in one contiguous block, so a wave walks its own few-KB region
+// sequentially instead of striding across the whole batch (used by the solve
+// workspace; DRAM pages and TLB entries are then reused from step to step).
+__device__ __forceinline__ int64_t bm_index(int64_t r, int64_t b, int64_t R, int64_t ld)
+{
+    return ld > 0 ? r * ld + b : ((b >> 6) * R + r) * 64 + (b & 63);
+}
+
+// ref [B, R] -> bm: 64x64 tile through LDS so both sides are coalesced.
 __global__ __launch_bounds__(256) void k_pack(const double* __restrict__ src, double* __restrict__ dst,
                                               int64_t B, int64_t R, int64_t ld)
 {
@@ -62,11 +72,23 @@ __global__ __launch_bounds__(256) void k_pack(const double* __restrict__ src, do
     for (int j = ty; j < 64; j += 4) {
         int64_t r = r0 + j, b = b0 + tx;
         if (r < R && b < B)
-            dst[r * ld + b] = tile[tx][j];
+            dst[bm_index(r, b, R, ld)] = tile[tx][j];
     }
 }
 
-// bm [R, ld] -> ref [B, R]; with sel != nullptr problem b reads srcB when sel[b] != 0.
+// ref [B, Rs] -> the first Rs rows of a wave-tiled array with Rd rows per tile.
+__global__ __launch_bounds__(256) void k_pack_rows(const double* __restrict__ src, double* __restrict__ dst,
+                                                   int64_t B, int64_t Rs, int64_t Rd)
+{
+    int64_t nblk = (int64_t)gridDim.x * gridDim.y;
+    int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    for (; i < B * Rs; i += nblk * 256) {
+        int64_t b = i / Rs, r = i % Rs;
+        dst[bm_index(r, b, Rd, 0)] = src[i];
+    }
+}
+
+// bm -> ref [B, R]; with sel != nullptr problem b reads srcB when sel[b] != 0.
 __global__ __launch_bounds__(256) void k_unpack(const double* __restrict__ srcA,
                                                 const double* __restrict__ srcB,
                                                 const int32_t* __restrict__ sel,
@@ -82,7 +104,7 @@ __global__ __launch_bounds__(256) void k_unpack(const double* __restrict__ srcA,
         src = srcB;
     for (int j = ty; j < 64; j += 4) {
         int64_t r = r0 + j;
-        tile[j][tx] = (r < R && bl < B) ? src[r * ld + bl] : 0.0;
+        tile[j][tx] = (r < R && bl < B) ? src[bm_index(r, bl, R, ld)] : 0.0;
     }
     __syncthreads();
     for (int j = ty; j < 64; j += 4) {
@@ -411,6 +433,10 @@ __global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP Cp, A
 
 // ------------------------------------------------------------- whole solve
 
+// Diagnostic: when set (ilqr_debug_wave_log), every wave of k_solve records its start
+// and end time (100 MHz real-time counter) and the hardware id of the SIMD it ran on.
+static __device__ unsigned long long* g_wave_log = nullptr;
+
 struct SolveBuffers {       // batch-minor workspace, two copies of everything that is swapped
     double* xs[2];          // [(T+1)*5, ld]
     double* us[2];          // [T, ld]
@@ -420,138 +446,255 @@ struct SolveBuffers {       // batch-minor workspace, two copies of everything t
     int32_t* sel_gain;      // [B] which copy holds the final gains
 };
 
+// Line-search candidates evaluated cooperatively by a wave in one pass.
+constexpr int LS_PASS = 8;   // problems per cooperative pass
+constexpr int LS_MAXA = 32;  // largest alpha schedule
+
 // iLQR.update_u (ilqr_core.py:241-399): every lane runs its own problem to
 // termination; no host involvement per iteration.
-template <class Cost>
-__global__ __launch_bounds__(WAVE) void k_solve(CartpoleP mp, QRCostP Cp, SolveOptsP O, BoundsP bd, int T,
-                                                int64_t B, int64_t ld, SolveBuffers W,
+//
+// Line search (:301-313).  The reference tries the alphas one after the other and
+// stops at the first hit; the first alpha is accepted in > 99.9 % of the iterations
+// of the cart-pole workloads.  Every lane therefore rolls out alpha_0 for its own
+// problem; the few problems that need more hand their remaining candidates to the
+// whole wave: each lane takes one (problem, alpha) pair, the costs land in LDS, and
+// the owner scans them in the reference's order.  The accept / reject decision and
+// every number are those of the serial loop (a rollout is a pure function of
+// (problem, alpha)); only the cost changes: a rejected iteration needs ~3 rollout
+// times instead of 30, which removes the straggler waves that otherwise set the
+// kernel's duration.
+// OCC = waves per SIMD the register budget is sized for: 1 (up to 512 registers, no
+// spills) while the batch gives every SIMD at most one wave, 2 beyond that.
+template <class Cost, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_solve(CartpoleP mp, QRCostP Cp, SolveOptsP O, BoundsP bd, int T,
+                                                int64_t B, SolveBuffers W,
                                                 double* __restrict__ delta_io,
                                                 double* __restrict__ J_out, double* __restrict__ mu_out,
                                                 int32_t* __restrict__ iters_out,
                                                 int32_t* __restrict__ status_out, ilqr_trace tr)
 {
-    int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
-    if (b >= B)
-        return;
+    __shared__ double s_alpha[LS_MAXA];
+    __shared__ double s_J[4][LS_PASS][LS_MAXA];
+    __shared__ int s_lane[4][LS_PASS], s_cur[4][LS_PASS], s_gcur[4][LS_PASS];
+
+    const int64_t gb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // problem index
+    const bool valid = gb < B;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6; // wave within the workgroup (each wave only talks to itself)
+    if (threadIdx.x < LS_MAXA)
+        s_alpha[threadIdx.x] = O.alphas[threadIdx.x];
+    __syncthreads();
+
+    unsigned long long* wave_log = g_wave_log;
+    if (wave_log != nullptr && lane == 0 && valid) {
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        wave_log[(gb >> 6) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        wave_log[(gb >> 6) * 4 + 2] = hw_id;
+        wave_log[(gb >> 6) * 4 + 3] = xcc;
+    }
+    // the workspace is wave-tiled: this wave's rows are contiguous, leading dimension 64.
+    // (Named pointers and selects, not arrays indexed by a lane-varying 0/1: a
+    // dynamically indexed pointer array would live in scratch memory.)
+    const int64_t tile = gb >> 6;
+    double* const xs0 = W.xs[0] + tile * (int64_t)(T + 1) * NX * 64;
+    double* const xs1 = W.xs[1] + tile * (int64_t)(T + 1) * NX * 64;
+    double* const us0 = W.us[0] + tile * (int64_t)T * 64;
+    double* const us1 = W.us[1] + tile * (int64_t)T * 64;
+    double* const k0 = W.k[0] + tile * (int64_t)T * 64;
+    double* const k1 = W.k[1] + tile * (int64_t)T * 64;
+    double* const K0 = W.K[0] + tile * (int64_t)T * NX * 64;
+    double* const K1 = W.K[1] + tile * (int64_t)T * NX * 64;
+#define XS(i) ((i) ? xs1 : xs0)
+#define US(i) ((i) ? us1 : us0)
+#define KF(i) ((i) ? k1 : k0)
+#define KG(i) ((i) ? K1 : K0)
+    const int64_t ld = 64;
+    const int64_t b = lane;
     CartpoleC P = cartpole_consts(mp);
     Cost C(Cp);
     QPOptsP QO = qp_opts_in_vgprs(O.qp);
     int cur = 0;  // trajectory copy in use
     int gcur = 0; // gain copy in use (holds the solver's k_/K_ on entry)
-    double mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
-    double delta = delta_io[b];
-
-    // initial rollout and cost (:269-271); us_init is in W.us[0], x0 in rows 0..4 of W.xs[0]
-    double J;
-    {
+    double mu = 1.0, delta = 2.0, J = 0.0;
+    if (valid) {
+        mu = O.mu_from_array ? mu_out[gb] : 1.0; // reset per call (:264); delta_ persists (:62)
+        delta = delta_io[gb];
+        // initial rollout and cost (:269-271); us_init is in W.us[0], x0 in rows 0..4 of W.xs[0]
         double x[NX], xn[NX];
-        load5(W.xs[0], ld, 0, b, x);
-        J = 0.0;
+        load5(xs0, ld, 0, b, x);
         for (int t = 0; t < T; ++t) {
-            double u = W.us[0][(int64_t)t * ld + b];
+            double u = us0[(int64_t)t * ld + b];
             if (t > 0)
-                store5(W.xs[0], ld, (int64_t)t * NX, b, x);
+                store5(xs0, ld, (int64_t)t * NX, b, x);
             J = J + C.l(x, u);
             cartpole_f(P, x, u, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i)
                 x[i] = xn[i];
         }
-        store5(W.xs[0], ld, (int64_t)T * NX, b, x);
+        store5(xs0, ld, (int64_t)T * NX, b, x);
         J = J + C.l_terminal(x);
     }
 
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
     int converged = 0, status = ILQR_RAN_OUT;
-    int it = 0;
-    for (it = 0; it < O.max_iter; ++it) {
-        const double* xs = W.xs[cur];
-        const double* us = W.us[cur];
-        // ---- backward pass, with the LinAlgError retry loop (:287-299)
+    int iters = 0;
+    bool running = valid && O.max_iter > 0;
+    const int n_more = O.n_alpha - 1; // candidates after alpha_0
+
+    for (int it = 0; it < O.max_iter; ++it) {
+        if (__ballot(running) == 0ull)
+            break;
         BwAcc S;
         int stopped_at = -1;
         S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
-        bool done = false;
-        while (!done) {
-            int gnew = gcur ^ 1;
-            int rc = backward_sweep<true, false>(P, C, QO, bd, T, ld, b, xs, us, mu, W.k[gnew], W.K[gnew], S,
-                                          stopped_at, nullptr, nullptr);
-            if (rc != BW_LINALG) {
-                gcur = gnew;
-                dJ1 = S.dJ1;
-                dJ2 = S.dJ2;
-                done = true;
+        int accepted = 0, j = 0;
+        double Jnew = 0.0;
+        const int nxt = cur ^ 1;
+        bool need = false; // the serial loop would go on to alpha_1
+        if (running) {
+            const double* xs = XS(cur);
+            const double* us = US(cur);
+            // ---- backward pass, with the LinAlgError retry loop (:287-299)
+            bool done = false;
+            while (!done) {
+                int gnew = gcur ^ 1;
+                int rc = backward_sweep<true, false>(P, C, QO, bd, T, ld, b, xs, us, mu, KF(gnew), KG(gnew),
+                                                     S, stopped_at, nullptr, nullptr);
+                if (rc != BW_LINALG) {
+                    gcur = gnew;
+                    dJ1 = S.dJ1;
+                    dJ2 = S.dJ2;
+                    done = true;
+                } else {
+                    delta = fmax(delta, 1.0) * O.delta0;
+                    mu = fmax(O.mu_min, mu * delta);
+                    if (O.mu_max != 0.0 && mu >= O.mu_max)
+                        break;
+                }
+            }
+            // ---- line search, alpha_0 (:301-313)
+            if (O.n_alpha > 0) {
+                double alpha = s_alpha[0];
+                Jnew = forward_rollout<true>(P, C, T, ld, b, xs, us, KF(gcur), KG(gcur), alpha, XS(nxt), US(nxt));
+                double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+                if (expected <= 0.0) {
+                    // reject the whole iteration
+                } else if ((J - Jnew) / expected > O.scale) {
+                    actual = J - Jnew;
+                    accepted = 1;
+                } else {
+                    need = n_more > 0;
+                    j = need ? 1 : O.n_alpha;
+                }
+            }
+        }
+        // ---- remaining alphas of the problems that need them, LS_PASS problems per pass
+        // (helper lanes read gains another lane of this wave has just stored)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        unsigned long long mask = __ballot(need);
+        bool redo = false; // accepted at some alpha_j, j >= 1: its trajectory still has to be written
+        while (mask != 0ull) {
+            int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            bool mine = need && rank < LS_PASS;
+            if (mine) {
+                s_lane[wv][rank] = lane;
+                s_cur[wv][rank] = cur;
+                s_gcur[wv][rank] = gcur;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int np = __popcll(mask);
+            np = np < LS_PASS ? np : LS_PASS;
+            int nc = np * n_more;
+            for (int q0 = 0; q0 < nc; q0 += 64) {
+                int q = q0 + lane;
+                if (q < nc) {
+                    int fi = q / n_more, jj = 1 + q % n_more;
+                    int64_t pb = s_lane[wv][fi];
+                    int pc = s_cur[wv][fi], pg = s_gcur[wv][fi];
+                    s_J[wv][fi][jj] = forward_rollout<false>(P, C, T, ld, pb, XS(pc), US(pc), KF(pg), KG(pg),
+                                                              s_alpha[jj], nullptr, nullptr);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                // the reference's loop from alpha_1 on, on the tabulated costs
+                for (j = 1; j < O.n_alpha; ++j) {
+                    double alpha = s_alpha[j];
+                    Jnew = s_J[wv][rank][j];
+                    double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+                    if (expected <= 0.0) {
+                        break;
+                    } else if ((J - Jnew) / expected > O.scale) {
+                        actual = J - Jnew;
+                        accepted = 1;
+                        redo = true;
+                        break;
+                    }
+                }
+                need = false;
+            }
+            __builtin_amdgcn_wave_barrier();
+            mask = __ballot(need);
+        }
+        if (redo) // the accepted candidate's states and controls (same arithmetic, same bits)
+            Jnew = forward_rollout<true>(P, C, T, ld, b, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(nxt),
+                                         US(nxt));
+        // ---- regularisation schedule and termination (:315-339)
+        if (running) {
+            bool stop = false;
+            if (accepted) {
+                delta = fmin(1.0, delta) / O.delta0;
+                mu = mu * delta;
+                if (mu <= O.mu_min)
+                    mu = 0.0;
+                J = Jnew;
+                cur = nxt;
+                if (actual < O.tol)
+                    converged = 1;
             } else {
                 delta = fmax(delta, 1.0) * O.delta0;
                 mu = fmax(O.mu_min, mu * delta);
-                if (O.mu_max != 0.0 && mu >= O.mu_max)
-                    break;
+                if (O.mu_max != 0.0 && mu >= O.mu_max) {
+                    status = ILQR_MU_MAX;
+                    stop = true;
+                }
             }
-        }
-        // ---- serial first-hit line search (:301-313)
-        int accepted = 0;
-        int j = 0;
-        double Jnew = 0.0;
-        int nxt = cur ^ 1;
-        for (j = 0; j < O.n_alpha; ++j) {
-            double alpha = O.alphas[j];
-            Jnew = forward_rollout<true>(P, C, T, ld, b, xs, us, W.k[gcur], W.K[gcur], alpha, W.xs[nxt],
-                                   W.us[nxt]);
-            double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
-            if (expected <= 0.0) {
-                break;
-            } else if ((J - Jnew) / expected > O.scale) {
-                actual = J - Jnew;
-                accepted = 1;
-                break;
-            }
-        }
-        // ---- regularisation schedule and termination (:315-339)
-        bool stop = false;
-        if (accepted) {
-            delta = fmin(1.0, delta) / O.delta0;
-            mu = mu * delta;
-            if (mu <= O.mu_min)
-                mu = 0.0;
-            J = Jnew;
-            cur = nxt;
-            if (actual < O.tol)
-                converged = 1;
-        } else {
-            delta = fmax(delta, 1.0) * O.delta0;
-            mu = fmax(O.mu_min, mu * delta);
-            if (O.mu_max != 0.0 && mu >= O.mu_max) {
-                status = ILQR_MU_MAX;
-                stop = true;
-            }
-        }
-        int64_t to = (int64_t)it * B + b;
-        if (tr.J) tr.J[to] = J;
-        if (tr.accepted) tr.accepted[to] = accepted;
-        if (tr.alpha_idx) tr.alpha_idx[to] = j;
-        if (tr.mu) tr.mu[to] = mu;
-        if (tr.delta) tr.delta[to] = delta;
-        if (tr.qp_iter) tr.qp_iter[to] = S.qp_iter;
-        if (tr.qp_backtrack) tr.qp_backtrack[to] = S.qp_backtrack;
-        if (tr.n_clamped) tr.n_clamped[to] = S.n_clamped;
-        if (tr.stopped_at) tr.stopped_at[to] = stopped_at;
-        if (stop) {
-            ++it;
-            break;
-        }
-        if (converged) {
-            status = ILQR_CONVERGED;
-            ++it;
-            break;
+            int64_t to = (int64_t)it * B + gb;
+            if (tr.J) tr.J[to] = J;
+            if (tr.accepted) tr.accepted[to] = accepted;
+            if (tr.alpha_idx) tr.alpha_idx[to] = j;
+            if (tr.mu) tr.mu[to] = mu;
+            if (tr.delta) tr.delta[to] = delta;
+            if (tr.qp_iter) tr.qp_iter[to] = S.qp_iter;
+            if (tr.qp_backtrack) tr.qp_backtrack[to] = S.qp_backtrack;
+            if (tr.n_clamped) tr.n_clamped[to] = S.n_clamped;
+            if (tr.stopped_at) tr.stopped_at[to] = stopped_at;
+            iters = it + 1;
+            if (converged)
+                status = ILQR_CONVERGED;
+            if (stop || converged)
+                running = false;
         }
     }
-    delta_io[b] = delta;
-    J_out[b] = J;
-    mu_out[b] = mu;
-    iters_out[b] = it;
-    status_out[b] = status;
-    W.sel_traj[b] = cur;
-    W.sel_gain[b] = gcur;
+    if (valid) {
+        delta_io[gb] = delta;
+        J_out[gb] = J;
+        mu_out[gb] = mu;
+        iters_out[gb] = iters;
+        status_out[gb] = status;
+        W.sel_traj[gb] = cur;
+        W.sel_gain[gb] = gcur;
+    }
+    if (wave_log != nullptr && lane == 0 && valid)
+        wave_log[(gb >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#undef XS
+#undef US
+#undef KF
+#undef KG
 }
 
 // ------------------------------------------------------- stand-alone boxQP
@@ -932,7 +1075,7 @@ int fill_qp(const ilqr_opts* o, QPOptsP& q)
 
 int fill_opts(const ilqr_opts* o, SolveOptsP& s)
 {
-    if (!o || !o->alphas || o->n_alpha < 0 || o->n_alpha > 32 || o->max_iter < 0)
+    if (!o || !o->alphas || o->n_alpha < 0 || o->n_alpha > LS_MAXA || o->max_iter < 0)
         return ILQR_ERR_ARG;
     s.max_iter = o->max_iter;
     s.n_alpha = o->n_alpha;
@@ -1143,29 +1286,48 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
     W.sel_traj = reinterpret_cast<int32_t*>(p);
     W.sel_gain = W.sel_traj + ld;
 
-    hipLaunchKernelGGL(k_pack, tile_grid(B, 5), dim3(256), 0, st, x0, W.xs[0], B, (int64_t)5, ld);
-    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, us_init, W.us[0], B, T, ld);
-    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, (const double*)k, W.k[0], B, T, ld);
-    hipLaunchKernelGGL(k_pack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)K, W.K[0], B, T * 5, ld);
+    const int64_t tiled = 0; // ld = 0 selects the wave-tiled layout (bm_index)
+    // x0 goes to rows 0..4 of the (T+1)*5-row state array of each tile
+    hipLaunchKernelGGL(k_pack_rows, tile_grid(B, 5), dim3(256), 0, st, x0, W.xs[0], B, (int64_t)5,
+                       (int64_t)(T + 1) * 5);
+    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, us_init, W.us[0], B, T, tiled);
+    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, (const double*)k, W.k[0], B, T, tiled);
+    hipLaunchKernelGGL(k_pack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)K, W.K[0], B, T * 5, tiled);
     ilqr_trace tr;
     if (trace)
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
-    if (use_diag(C))
-        hipLaunchKernelGGL(k_solve<DiagQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, mp, C, O,
-                           bd, (int)T, B, ld, W, delta, J, mu, iters, status, tr);
+    // Workgroup shape: one wave per workgroup spreads a small batch over all CUs; with
+    // more than one wave per CU to place, 4-wave workgroups put one wave on each SIMD.
+    int blk = B > 64 * 256 ? 256 : WAVE;
+    if (const char* e = std::getenv("ILQR_SOLVE_BLOCK"))
+        blk = std::atoi(e) == 256 ? 256 : WAVE;
+    dim3 grid((unsigned)((B + blk - 1) / blk));
+    int occ = B > 64 * 1024 ? 2 : 1; // more than one wave per SIMD to place?
+    if (const char* e = std::getenv("ILQR_SOLVE_OCC"))
+        occ = std::atoi(e) == 2 ? 2 : 1;
+    bool diag = use_diag(C);
+#define ILQR_LAUNCH_SOLVE(COST, OCC)                                                                          \
+    hipLaunchKernelGGL((k_solve<COST, OCC>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, \
+                       iters, status, tr)
+    if (diag && occ == 1)
+        ILQR_LAUNCH_SOLVE(DiagQR, 1);
+    else if (diag)
+        ILQR_LAUNCH_SOLVE(DiagQR, 2);
+    else if (occ == 1)
+        ILQR_LAUNCH_SOLVE(DenseQR, 1);
     else
-        hipLaunchKernelGGL(k_solve<DenseQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, mp, C, O,
-                           bd, (int)T, B, ld, W, delta, J, mu, iters, status, tr);
+        ILQR_LAUNCH_SOLVE(DenseQR, 2);
+#undef ILQR_LAUNCH_SOLVE
     hipLaunchKernelGGL(k_unpack, tile_grid(B, (T + 1) * 5), dim3(256), 0, st, (const double*)W.xs[0],
-                       (const double*)W.xs[1], (const int32_t*)W.sel_traj, xs, B, (T + 1) * 5, ld);
+                       (const double*)W.xs[1], (const int32_t*)W.sel_traj, xs, B, (T + 1) * 5, tiled);
     hipLaunchKernelGGL(k_unpack, tile_grid(B, T), dim3(256), 0, st, (const double*)W.us[0],
-                       (const double*)W.us[1], (const int32_t*)W.sel_traj, us, B, T, ld);
+                       (const double*)W.us[1], (const int32_t*)W.sel_traj, us, B, T, tiled);
     hipLaunchKernelGGL(k_unpack, tile_grid(B, T), dim3(256), 0, st, (const double*)W.k[0],
-                       (const double*)W.k[1], (const int32_t*)W.sel_gain, k, B, T, ld);
+                       (const double*)W.k[1], (const int32_t*)W.sel_gain, k, B, T, tiled);
     hipLaunchKernelGGL(k_unpack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)W.K[0],
-                       (const double*)W.K[1], (const int32_t*)W.sel_gain, K, B, T * 5, ld);
+                       (const double*)W.K[1], (const int32_t*)W.sel_gain, K, B, T * 5, tiled);
     return hip_status(hipGetLastError());
 }
 
@@ -1189,6 +1351,12 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
         hipLaunchKernelGGL(k_boxqp, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, as_stream(stream), q,
                            B, (int)m, H, g, lower, upper, x0, x, result, Hff, hff_dim, free_mask, counters);
     return hip_status(hipGetLastError());
+}
+
+int ilqr_debug_wave_log(void* device_buffer)
+{
+    unsigned long long* p = static_cast<unsigned long long*>(device_buffer);
+    return hip_status(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_log), &p, sizeof(p)));
 }
 
 int ilqr_cartpole_plant_step(int64_t B, const double* par, const double* st, const double* u, double* out,

@@ -179,6 +179,12 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
 int ilqr_cartpole_plant_step(int64_t B, const double* par, const double* st, const double* u,
                              double* out, void* stream);
 
+/* Diagnostic hook (no counterpart in the reference): with a device buffer of
+ * 4 * ceil(B/64) uint64 set, every wavefront of the next ilqr_solve_batched launches
+ * records [start, end] of its life in 100 MHz ticks, its HW_ID and its XCC id.
+ * NULL switches the log off.  Synchronous (hipMemcpyToSymbol). */
+int ilqr_debug_wave_log(void* device_buffer);
+
 /* Test hook: the library's own sin/cos/atan2 on arrays (a, b) -> sin a, cos a, atan2(a, b). */
 int ilqr_detmath(int64_t n, const double* a, const double* b, double* sin_a, double* cos_a,
                  double* atan2_ab, double* sqrt_abs_a, double* a_over_b, void* stream);

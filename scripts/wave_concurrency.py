@@ -1,0 +1,37 @@
+"""Diagnostic: how many wavefronts of the solve kernel are alive at the same time."""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ilqr_amd import _hip
+import bench
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+dev = torch.device("cuda:0")
+Q, R, Qt, xg = bench.cartpole_cost()
+M = _hip.Model(100, Q, R, Qt, xg, None, [-5.0], [5.0])
+x0_h, us_h = bench.make_batch(B, 0)
+x0 = torch.tensor(x0_h, device=dev); us = torch.tensor(us_h, device=dev)
+nw = (B + 63) // 64
+log = torch.zeros((nw, 4), dtype=torch.int64, device=dev)
+O = _hip.Opts()
+_hip.solve(M, O, x0, us); torch.cuda.synchronize()
+_hip.check(_hip.lib().ilqr_debug_wave_log(C.c_void_p(log.data_ptr())))
+res = _hip.solve(M, O, x0, us); torch.cuda.synchronize()
+_hip.check(_hip.lib().ilqr_debug_wave_log(None))
+L = log.cpu().numpy()
+t0 = L[:, 0].min()
+start = (L[:, 0] - t0) / 1e5  # ms (100 MHz)
+end = (L[:, 1] - t0) / 1e5
+print("waves", nw, "kernel span %.1f ms" % end.max(), "wave life: mean %.1f min %.1f max %.1f ms" % ((end - start).mean(), (end - start).min(), (end - start).max()))
+print("start times: %.1f%% within first 1 ms; latest start %.1f ms" % (100 * (start < 1).mean(), start.max()))
+for t in (1, 50, 100, 150, 200, 300, 400, 500):
+    print("  alive at %3d ms: %d" % (t, int(((start <= t) & (end > t)).sum())))
+hw = L[:, 2]
+cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
+key = L[:, 3] * 100000 + se * 10000 + sh * 1000 + cu * 10 + simd
+first = start < 1
+print("distinct SIMDs used by waves started in the first ms:", len(np.unique(key[first])), "of", int(first.sum()), "waves")
+print("distinct CUs:", len(np.unique(key[first] // 10)))
+iters = res["iters"].cpu().numpy().reshape(nw, -1).max(axis=1)
+print("per-wave max iterations: min %d mean %.1f" % (iters.min(), iters.mean()))
