@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="problems per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

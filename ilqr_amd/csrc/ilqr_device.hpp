@@ -59,7 +59,27 @@ struct QPOptsP { // ilqr_core.py:154-155
     int n_exhaust;    // number of step reductions after which step < min_step (host-simulated)
     double step_last; // the step after n_exhaust reductions
     double min_grad, min_rel, step_dec, min_step, armijo;
+    int tab_n;          // entries of the step table the Armijo search may jump to: min(n_exhaust, QP_TAB)
+    float inv_log2_dec; // 1 / log2(step_dec), for the (unverified, fp32) estimate of the jump target
 };
+
+// The Armijo steps 1, dec, dec*dec, ... exactly as the loop's repeated rounded
+// multiplication produces them (ilqr_boxQP.py:151), so that the search can resume
+// at trip t with the very bits the literal loop would hold there.  One table per
+// workgroup, in LDS, filled once at kernel start.
+constexpr int QP_TAB = 512;
+
+__device__ __forceinline__ void qp_fill_step_table(double* tab, double step_dec)
+{
+    if (threadIdx.x == 0) {
+        double s = 1.0;
+        for (int t = 0; t < QP_TAB; ++t) {
+            tab[t] = s;
+            s = s * step_dec;
+        }
+    }
+    __syncthreads();
+}
 
 __device__ __forceinline__ QPOptsP qp_opts_in_vgprs(const QPOptsP& o)
 {
@@ -370,6 +390,52 @@ __device__ __forceinline__ bool quotient_below(double num, double den, double a)
     return below;
 }
 
+// ---- proofs used by the Armijo search of boxqp1 -------------------------------
+//
+// Notation.  x, grad, search, oldvalue are fixed during one search; a candidate is
+// xc = clamp(x + step * search), d = xc - x (exact), u = |d|, eps = 1e-10, a = the
+// Armijo constant in (0, 1), G = |computed grad|, gerr >= |computed - exact grad|.
+// In exact arithmetic  value(xc) - value(x) = d * grad + H d^2 / 2.  The test of
+// ilqr_boxQP.py:151 continues while  num / den < a  with
+//   num = fl(value(xc)) - fl(value(x)),   den = fl(fl(d) * grad) + eps.
+// |num - (d grad + H d^2 / 2)| <= 2e-15 (X |g| + H X^2) for |x|, |xc| <= X (rounding of
+// the two quadratic evaluations and of their difference); den carries a relative
+// error of a few ulp.  qp_error_budget() returns a bound Ep on every rounding term
+// that enters the two proofs below (including the rounding of evaluating h itself),
+// for candidates with u <= D.
+//
+// With d * grad = -u G (descent):  num - a den = h(u) + rounding,
+//   h(u) = H u^2 / 2 - (1 - a) G u - a eps,   convex, h(0) < 0.
+//  * den > 0 (u G < eps):  continue  <=>  num < a den  <=>  h(u) < 0.  If that holds at
+//    u = D with margin Ep it holds on all of [0, D] (convexity), i.e. for every later,
+//    shorter candidate: the loop can only end by step < min_step.   [spin]
+//  * den < 0 (u G > eps):  continue  <=>  num > a den  <=>  h(u) > 0.  If that holds at
+//    u = uv with margin Ep it holds for every u >= uv (h increases beyond its root),
+//    i.e. for every EARLIER, longer candidate: u is monotone in step because rounding,
+//    clamping and the products by fixed numbers are monotone.        [jump]
+// Without a sure sign of d * grad the spin proof uses the bounds  num <= u G + H u^2 / 2,
+// den >= eps - u G  instead.
+
+__device__ __forceinline__ double qp_error_budget(const QPOptsP& O, double H, double g, double ax, double G,
+                                                  double gerr, double D)
+{
+    double X = ax + D;
+    return 2e-15 * (X * fabs(g) + (H * X) * X) + 1e-14 * ((0.5 * H * D) * D + D * G + O.armijo * 1e-10) +
+           2.0 * (D * gerr);
+}
+
+// True only if every candidate with |xc - x| <= D fails the Armijo test (so the
+// search ends at step < min_step with result 2, ilqr_boxQP.py:153-156).
+__device__ __forceinline__ bool qp_spin_proved(const QPOptsP& O, double H, double G, double gerr, bool descent,
+                                               double D, double Ep)
+{
+    double q = (0.5 * H * D) * D;
+    double lin = descent ? -((1.0 - O.armijo) * (G - gerr)) : (1.0 + O.armijo) * (G + gerr);
+    double hD = (q + lin * D) - O.armijo * 1e-10;
+    bool den_pos = (D * (G + gerr)) * 1.000000001 < 0.999999999e-10;
+    return den_pos & (hD + Ep < 0.0) & (Ep < O.armijo * 1e-10);
+}
+
 struct QP1Out {
     double x;      // solution
     double rdiag;  // reciprocal of the 1x1 free-subspace Cholesky factor (1.0: never factorised, H_ff = ones)
@@ -384,8 +450,9 @@ struct QP1Out {
 // un-factorised H_ff = ones (:36, :108-117).
 // sqrtH, rsqrtH: sqrt(H) and 1.0 / sqrt(H) as the caller already has them from
 // its own Cholesky of the same 1x1 matrix (same input, same bits).
-__device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double sqrtH, double rsqrtH, double g,
-                                       double lo, double hi, double x0, QP1Out& out)
+// tab: the workgroup's step table (qp_fill_step_table).
+__device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, double H, double sqrtH, double rsqrtH,
+                                       double g, double lo, double hi, double x0, QP1Out& out)
 {
     bool clamped = false, free_ = false;
     double oldvalue = 0.0;
@@ -433,46 +500,71 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, double H, double sqrtH,
         double search = sol * -1 - x;
 
         // Armijo line search (:140-159), written with selects and a single loop exit.
-        // Two early exits replace, without changing any result, the hundreds of
-        // reductions the reference spins through until step < minStep when the test
-        // has become unsatisfiable.  Both end exactly where the literal loop ends:
-        // result 2, n_exhaust reductions counted, candidate evaluated at the last step
-        // of the geometric sequence (step_last); n_exhaust and step_last are constants
-        // of (stepDec, minStep) computed on the host with the same rounded products.
-        //  (a) fixed point: x + step*search clamps (or rounds) back to x, and does so
-        //      for every smaller step; then vc == oldvalue, sdotg == 0, ratio == 0.
-        //  (b) the 1e-10 in the denominator: with d = xc' - x for any later candidate,
-        //      |d| <= D, so  sdotg' + 1e-10 >= 1e-10 - 1.001 D |grad| >= 0.5e-10  and
-        //      vc' - oldvalue <= D |grad| + H D^2 / 2 + rounding =: N  (rounding of the
-        //      two quadratic evaluations is below 1e-15 (X |g| + H X^2), X = |x| + D).
-        //      If N <= 0.49e-10 * Armijo every later ratio is below Armijo whatever the
-        //      rounding of the division.  Checked every 4th reduction from the 20th on.
+        // The reference walks step = 1, dec, dec^2, ... and tests every candidate; a
+        // typical first pass (un-factorised, H_ff = ones) rejects a dozen of them and a
+        // converged problem spins through all n_exhaust.  Both are cut short here by
+        // PROOFS about the outcome of the skipped tests, so that no result, counter or
+        // bit changes (see qp_spin_proved and the jump below).
         double step = 1.0;
         int nstep = 0;
         double xc = clamp1(lo, hi, x + step * search);
         double sdotg = (xc - x) * grad;
         double vc = qp_value1(H, g, xc);
         bool more = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo);
-        int trip = 0; // same for every lane still in the loop
-        while (more) {
-            bool exhaust = (xc == x);
-            if (trip >= 20 && (trip & 3) == 0) {
-                double ax = fabs(x), ag = fabs(grad);
-                double D = 1.001 * (step * fabs(search)) + 4e-16 * ax;
-                double X = ax + D;
-                double gt = ag + 5e-16 * (fabs(g) + fabs(H * x));
-                double N = 1.001 * (D * gt + 0.5 * H * D * D) + 1e-15 * (X * fabs(g) + H * X * X);
-                exhaust = exhaust | ((O.armijo > 0.0) & (D * ag <= 0.49e-10) & (N <= 0.49e-10 * O.armijo));
+        if (__ballot(more) != 0ull) {
+            double ax = fabs(x), G = fabs(grad), as = fabs(search);
+            double gerr = 5e-16 * (fabs(g) + fabs(H * x)); // |computed grad - exact g + H x| stays below this
+            bool descent = (((search > 0.0) & (grad < 0.0)) | ((search < 0.0) & (grad > 0.0))) & (G > 4.0 * gerr);
+            bool a_ok = (O.armijo > 0.0) & (O.armijo < 1.0);
+            double D0 = 1.001 * as + 4e-16 * ax; // |xc' - x| <= D0 for this and every later candidate
+            double Ep = qp_error_budget(O, H, g, ax, G, gerr, D0);
+            bool exhaust = more & ((xc == x) | (a_ok & qp_spin_proved(O, H, G, gerr, descent, D0, Ep)));
+            // Jump: the search may resume at trip tj if every trip before it provably
+            // continues.  tj comes from an fp32 estimate of where the test flips (its
+            // accuracy only decides how much is skipped); the proof is evaluated in fp64
+            // at trip tj - 1 and covers all earlier trips by monotonicity.
+            float Gf = (float)G, Hf = (float)H, cf = (float)(1.0 - O.armijo);
+            float up = (cf * Gf + __builtin_sqrtf(cf * cf * Gf * Gf + (float)(2e-10 * O.armijo) * Hf)) / Hf;
+            float U = fmaxf(up, 1e-10f / Gf);
+            float tf = __log2f(U / (float)as) * O.inv_log2_dec;
+            tf = fminf(fmaxf(tf, 0.0f), 1.0e6f); // NaN -> 0
+            int tj = (int)tf + 1;
+            tj = tj < O.tab_n ? tj : O.tab_n - 1;
+            bool try_jump = more & !exhaust & descent & a_ok & (tj >= 2);
+            tj = try_jump ? tj : 1;
+            double sv = tab[tj - 1], sj = tab[tj];
+            double xv = clamp1(lo, hi, x + sv * search);
+            double dv = xv - x, uv = fabs(dv);
+            double hv = (0.5 * H * uv) * uv - ((1.0 - O.armijo) * (G + gerr)) * uv - O.armijo * 1e-10;
+            bool jump = try_jump & (hv > Ep) & (fabs(dv * grad) > 1.0000001e-10);
+            step = exhaust ? O.step_last : (jump ? sj : step);
+            nstep = exhaust ? O.n_exhaust : (jump ? tj : nstep);
+            result = exhaust ? 2 : result;
+            if (__ballot(exhaust | jump) != 0ull) {
+                double xn = clamp1(lo, hi, x + step * search);
+                xc = (exhaust | jump) ? xn : xc;
+                vc = qp_value1(H, g, xc);
+                sdotg = (xc - x) * grad;
+                bool m2 = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo);
+                more = exhaust ? false : (jump ? m2 : more);
             }
-            step = exhaust ? O.step_last : step * O.step_dec;
-            nstep = exhaust ? O.n_exhaust : nstep + 1;
-            ++trip;
-            xc = clamp1(lo, hi, x + step * search);
-            vc = qp_value1(H, g, xc);
-            sdotg = (xc - x) * grad;
-            bool ended = exhaust | (step < O.min_step);
-            result = ended ? 2 : result;
-            more = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo) & !ended;
+            int trip = 0; // same for every lane still in the loop
+            while (more) {
+                bool ex = (xc == x);
+                if ((trip & 3) == 3) {
+                    double D = 1.001 * (step * as) + 4e-16 * ax;
+                    ex = ex | (a_ok & qp_spin_proved(O, H, G, gerr, descent, D, qp_error_budget(O, H, g, ax, G, gerr, D)));
+                }
+                step = ex ? O.step_last : step * O.step_dec;
+                nstep = ex ? O.n_exhaust : nstep + 1;
+                ++trip;
+                xc = clamp1(lo, hi, x + step * search);
+                vc = qp_value1(H, g, xc);
+                sdotg = (xc - x) * grad;
+                bool ended = ex | (step < O.min_step);
+                result = ended ? 2 : result;
+                more = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo) & !ended;
+            }
         }
         n_bt += nstep;
         x = xc;
@@ -520,7 +612,7 @@ __device__ __forceinline__ void bw_init(const Cost& C, const double (&xT)[NX], B
 // warns and breaks, :137-140) or BW_LINALG (eigvals would raise on a non-finite
 // Q_uu, :291).
 template <class Cost>
-__device__ __forceinline__ int bw_step(const Cost& C, const QPOptsP& QO, const CartpoleJac& J, double dt,
+__device__ __forceinline__ int bw_step(const Cost& C, const QPOptsP& QO, const double* tab, const CartpoleJac& J, double dt,
                                        const double (&x)[NX], double u, double mu, double lower,
                                        double upper, BwAcc& S, double& k_out, double (&K_out)[NX],
                                        int& qp_result, bool& qp_free)
@@ -611,7 +703,7 @@ __device__ __forceinline__ int bw_step(const Cost& C, const QPOptsP& QO, const C
 
     // boxQP(Q_uu, Q_u, lower - u, upper - u, k[i], ...)     (:152-156)
     QP1Out qp;
-    boxqp1(QO, Quu, L, rL, Qu, lower - u, upper - u, k0, qp);
+    boxqp1(QO, tab, Quu, L, rL, Qu, lower - u, upper - u, k0, qp);
     double kk = qp.x;
     S.qp_iter += qp.n_iter;
     S.qp_backtrack += qp.n_backtrack;

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP Cp, int T, 
 // stay in flight while step i computes instead of draining the queue.)
 template <bool TRUST_NEXT, bool RECORD, class Cost>
 __device__ __forceinline__ int backward_sweep(const CartpoleC& P, const Cost& C, const QPOptsP& QO,
-                                              const BoundsP& bd, int T, int64_t ld, int64_t b,
+                                              const double* qp_tab, const BoundsP& bd, int T, int64_t ld, int64_t b,
                                               const double* __restrict__ xs,
                                               const double* __restrict__ us, double mu,
                                               double* __restrict__ k, double* __restrict__ K,
@@ -270,7 +270,7 @@ __device__ __forceinline__ int backward_sweep(const CartpoleC& P, const Cost& C,
             double kt, Kt[NX];
             int qr;
             bool qf;
-            int r = bw_step(C, QO, J, P.dt, x, u, mu, bd.lo, bd.hi, S, kt, Kt, qr, qf);
+            int r = bw_step(C, QO, qp_tab, J, P.dt, x, u, mu, bd.lo, bd.hi, S, kt, Kt, qr, qf);
             if (r == BW_OK) {
                 kk = kt;
 #pragma unroll
@@ -318,6 +318,8 @@ __global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP Cp, QPO
                                                    double* __restrict__ dJ, int32_t* __restrict__ info,
                                                    int32_t* qp_result_bm, int32_t* free_bm)
 {
+    __shared__ double s_qp_tab[QP_TAB];
+    qp_fill_step_table(s_qp_tab, QOp.step_dec);
     int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
     if (b >= B)
         return;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP Cp, QPO
     QPOptsP QO = qp_opts_in_vgprs(QOp);
     BwAcc S;
     int stopped_at;
-    int rc = backward_sweep<false, RECORD>(P, C, QO, bd, T, ld, b, xs, us, mu[b], k, K, S, stopped_at,
+    int rc = backward_sweep<false, RECORD>(P, C, QO, s_qp_tab, bd, T, ld, b, xs, us, mu[b], k, K, S, stopped_at,
                                    qp_result_bm, free_bm);
     dJ[b] = S.dJ1;
     dJ[ld + b] = S.dJ2;
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(256, OCC) void k_solve(CartpoleP mp, QRCostP Cp, So
     __shared__ double s_alpha[LS_MAXA];
     __shared__ double s_J[4][LS_PASS][LS_MAXA];
     __shared__ int s_lane[4][LS_PASS], s_cur[4][LS_PASS], s_gcur[4][LS_PASS];
+    __shared__ double s_qp_tab[QP_TAB];
 
     const int64_t gb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // problem index
     const bool valid = gb < B;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256, OCC) void k_solve(CartpoleP mp, QRCostP Cp, So
     const int wv = threadIdx.x >> 6; // wave within the workgroup (each wave only talks to itself)
     if (threadIdx.x < LS_MAXA)
         s_alpha[threadIdx.x] = O.alphas[threadIdx.x];
-    __syncthreads();
+    qp_fill_step_table(s_qp_tab, O.qp.step_dec); // ends with the workgroup barrier
 
     unsigned long long* wave_log = g_wave_log;
     if (wave_log != nullptr && lane == 0 && valid) {
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(256, OCC) void k_solve(CartpoleP mp, QRCostP Cp, So
             bool done = false;
             while (!done) {
                 int gnew = gcur ^ 1;
-                int rc = backward_sweep<true, false>(P, C, QO, bd, T, ld, b, xs, us, mu, KF(gnew), KG(gnew),
+                int rc = backward_sweep<true, false>(P, C, QO, s_qp_tab, bd, T, ld, b, xs, us, mu, KF(gnew), KG(gnew),
                                                      S, stopped_at, nullptr, nullptr);
                 if (rc != BW_LINALG) {
                     gcur = gnew;
@@ -919,6 +922,8 @@ __global__ __launch_bounds__(256) void k_boxqp1(QPOptsP O, int64_t B, const doub
                                                 double* __restrict__ Hff_out, int32_t* __restrict__ hd_out,
                                                 int32_t* __restrict__ free_out, int32_t* __restrict__ cnt_out)
 {
+    __shared__ double s_qp_tab[QP_TAB];
+    qp_fill_step_table(s_qp_tab, O.step_dec);
     int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= B)
         return;
@@ -926,7 +931,7 @@ __global__ __launch_bounds__(256) void k_boxqp1(QPOptsP O, int64_t B, const doub
     double lo = lower[q], hi = upper[q];
     double xs = x0 ? x0[q] : (lo + hi) / 2;
     double sq = sqrt(H[q]);
-    boxqp1(O, H[q], sq, 1.0 / sq, g[q], lo, hi, xs, out);
+    boxqp1(O, s_qp_tab, H[q], sq, 1.0 / sq, g[q], lo, hi, xs, out);
     if (!(fabs(H[q]) < __builtin_inf()) && O.max_iter > 0) {
         // non-finite H: the first pass either finds everything clamped (:92) or
         // np.linalg.eigvals raises (:103); boxqp1 is written for the finite H the
@@ -1070,6 +1075,8 @@ int fill_qp(const ilqr_opts* o, QPOptsP& q)
     } while (!(step < o->qp_min_step) && n < 1000000);
     q.n_exhaust = n;
     q.step_last = step;
+    q.tab_n = n < QP_TAB ? n : QP_TAB;
+    q.inv_log2_dec = (float)(1.0 / std::log2(o->qp_step_dec));
     return ILQR_OK;
 }
 

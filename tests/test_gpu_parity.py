@@ -258,6 +258,40 @@ def test_boxqp_batched_random_bit_exact(hip):
         assert np.array_equal(out["counters"].cpu().numpy()[:, 2], ref["n_backtrack"])
 
 
+@pytest.mark.parametrize("step_dec,armijo,min_step", [(0.9, 0.1, 1e-22), (0.6, 0.1, 1e-22), (0.5, 0.4, 1e-12),
+                                                      (0.97, 0.01, 1e-8), (0.9, 0.0, 1e-22), (0.9, 1.5, 1e-6)])
+def test_boxqp1_shortcuts_over_magnitudes(hip, step_dec, armijo, min_step):
+    """The m = 1 routine skips Armijo trips whose outcome it can prove (jump to the trip
+    where the test flips, early exit from a search that cannot succeed).  Scalar QPs
+    over 30 decades of curvature and gradient, warm starts near and far from the
+    optimum and from the bounds: result, solution bits and the backtrack COUNT must be
+    those of the literal loop, for several option sets (including Armijo constants
+    outside (0, 1), for which no shortcut applies)."""
+    r = np.random.RandomState(17)
+    B = 200000
+    H = 10.0 ** r.uniform(-6, 11, B)
+    g_ = r.choice([-1.0, 1.0], B) * 10.0 ** r.uniform(-12, 6, B)
+    lo = -10.0 ** r.uniform(-3, 1, B)
+    up = 10.0 ** r.uniform(-3, 1, B)
+    opt = np.clip(-g_ / H, lo, up)
+    kind = r.randint(0, 5, B)
+    x0 = np.select([kind == 0, kind == 1, kind == 2, kind == 3],
+                   [g_ / H,                                        # the backward pass's warm start (ilqr_core.py:145)
+                    opt * (1 + 10.0 ** r.uniform(-16, -1, B)),     # next to the optimum
+                    opt + r.choice([-1, 1], B) * 10.0 ** r.uniform(-12, 0, B),
+                    np.where(r.uniform(size=B) < 0.5, lo, up)], r.randn(B) * 3)
+    kw = dict(qp_step_dec=step_dec, qp_armijo=armijo, qp_min_step=min_step)
+    sh = (B, 1)
+    ref = co.boxqp(H.reshape(B, 1, 1), g_.reshape(sh), lo.reshape(sh), up.reshape(sh), x0.reshape(sh), co.Opts(**kw))
+    out = hip.boxqp_batched(dev(H.reshape(B, 1, 1)), dev(g_.reshape(sh)), dev(lo.reshape(sh)), dev(up.reshape(sh)),
+                            dev(x0.reshape(sh)), hip.Opts(**kw))
+    assert np.array_equal(out["result"].cpu().numpy(), ref["result"])
+    assert eq(out["x"].cpu().numpy(), ref["x"])
+    cnt = out["counters"].cpu().numpy()
+    assert np.array_equal(cnt[:, 0], ref["n_iter"]) and np.array_equal(cnt[:, 2], ref["n_backtrack"])
+    assert len(set(ref["result"].tolist())) >= 3
+
+
 def test_plant_step_bit_exact(hip):
     r = np.random.RandomState(8)
     st = r.uniform(-3, 3, (1000, 4))
