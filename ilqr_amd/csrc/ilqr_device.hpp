@@ -523,10 +523,12 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
             // continues.  tj comes from an fp32 estimate of where the test flips (its
             // accuracy only decides how much is skipped); the proof is evaluated in fp64
             // at trip tj - 1 and covers all earlier trips by monotonicity.
+            // (hardware reciprocal / square root / log2 approximations: the estimate needs no accuracy)
             float Gf = (float)G, Hf = (float)H, cf = (float)(1.0 - O.armijo);
-            float up = (cf * Gf + __builtin_sqrtf(cf * cf * Gf * Gf + (float)(2e-10 * O.armijo) * Hf)) / Hf;
-            float U = fmaxf(up, 1e-10f / Gf);
-            float tf = __log2f(U / (float)as) * O.inv_log2_dec;
+            float cg = cf * Gf;
+            float up = (cg + __builtin_amdgcn_sqrtf(cg * cg + (float)(2e-10 * O.armijo) * Hf)) * __builtin_amdgcn_rcpf(Hf);
+            float U = fmaxf(up, 1e-10f * __builtin_amdgcn_rcpf(Gf));
+            float tf = __builtin_amdgcn_logf(U * __builtin_amdgcn_rcpf((float)as)) * O.inv_log2_dec;
             tf = fminf(fmaxf(tf, 0.0f), 1.0e6f); // NaN -> 0
             int tj = (int)tf + 1;
             tj = tj < O.tab_n ? tj : O.tab_n - 1;
