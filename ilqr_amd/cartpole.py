@@ -92,9 +92,16 @@ class CartPoleDynamics(Dynamics):
     def augment_state(cls, state):
         """[x, x', theta, theta'] -> [x, x', sin(theta), cos(theta), theta'] (1-D or 2-D)."""
         if _is_torch(state):
+            # device tensors stay on the device; sin / cos are the library's own (the functions
+            # the solver kernels use), so a closed loop kept on the GPU is reproducible bit for bit
             import torch
-            return torch.stack([state[..., 0], state[..., 1], torch.sin(state[..., 2]), torch.cos(state[..., 2]),
-                                state[..., 3]], dim=-1)
+            from . import _hip
+            theta = state[..., 2].to(torch.float64).contiguous()
+            if theta.is_cuda:
+                sin_t, cos_t = _hip.detmath(theta, theta)[:2]
+            else:
+                sin_t, cos_t = torch.sin(theta), torch.cos(theta)
+            return torch.stack([state[..., 0], state[..., 1], sin_t, cos_t, state[..., 3]], dim=-1)
         state = np.asarray(state, dtype=np.float64)
         if state.ndim == 1:
             x, x_dot, theta, theta_dot = state
@@ -110,8 +117,10 @@ class CartPoleDynamics(Dynamics):
         """[x, x', sin(theta), cos(theta), theta'] -> [x, x', theta, theta'] (1-D or 2-D)."""
         if _is_torch(state):
             import torch
-            return torch.stack([state[..., 0], state[..., 1], torch.atan2(state[..., 2], state[..., 3]),
-                                state[..., 4]], dim=-1)
+            from . import _hip
+            s_, c_ = state[..., 2].to(torch.float64).contiguous(), state[..., 3].to(torch.float64).contiguous()
+            theta = _hip.detmath(s_, c_)[2] if s_.is_cuda else torch.atan2(s_, c_)
+            return torch.stack([state[..., 0], state[..., 1], theta, state[..., 4]], dim=-1)
         state = np.asarray(state, dtype=np.float64)
         if state.ndim == 1:
             x, x_dot, sin_theta, cos_theta, theta_dot = state

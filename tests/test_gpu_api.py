@@ -157,6 +157,44 @@ def test_receding_horizon_closed_loop_against_reference_run(golden_dir):
         ctrl.set_state(dyn.augment_state(st))
 
 
+def test_mpc_full_size_closed_loops_on_device():
+    """4096 closed loops (the MPC configuration of the examples: N=15, 200 then 10 iterations
+    per control step, plant in the loop), tensors resident on the GPU.  Sampled loops must equal
+    the oracle's closed loop bit for bit (same deterministic sin/cos in augment_state), a slice
+    of the batch must equal the batch, and the loops must stay bounded."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import mpc_closed_loop as mpc
+    B, steps, N = 4096, 40, 15
+    res = mpc.run(B=B, steps=steps, N=N, record=True)
+    assert res["states"].shape == (steps + 1, B, 4) and np.isfinite(res["states"]).all()
+    assert res["iterations"][0].max() <= 200 and res["iterations"][1:].max() <= 10
+    # (with this horizon and force limit the example's controller does not swing the pole up: like
+    # the recorded reference run, the loops settle near theta = pi with the cart within a metre or two)
+    assert np.abs(res["final_state"][:, 0]).max() < 5.0 and np.abs(res["final_state"][:, 2] - np.pi).max() < 1.0
+
+    def oracle_augment(st):
+        s, c, _ = co.detmath(st[:, 2], st[:, 2])
+        return np.stack([st[:, 0], st[:, 1], s, c, st[:, 3]], axis=1)
+    pick = np.r_[0:8, B - 8:B]
+    st_all, us_all = mpc.initial_conditions(B, N)
+    st, us = st_all[pick], us_all[pick]
+    Mo = co.cartpole_model(T=N, max_control=20.0, l=0.5, mpc=True)
+    delta = k = K = None
+    n_it = 200
+    for s_ in range(steps):
+        ref = co.solve(Mo, co.Opts(max_iter=n_it), oracle_augment(st), us, delta=delta, k=k, K=K, nthreads=8,
+                       trace=False)
+        assert eq(res["controls"][s_][pick], ref["us"][:, 0, 0]), s_
+        assert np.array_equal(res["iterations"][s_][pick], ref["iters"])
+        delta, k, K = ref["delta"], ref["k"], ref["K"]
+        st = co.plant_step(st, ref["us"][:, 0, 0])
+        assert eq(res["states"][s_ + 1][pick], st)
+        us = np.concatenate([ref["us"][:, 1:], ref["us"][:, -1:]], axis=1)
+        n_it = 10
+
+
 def test_boxqp_api(golden_dir):
     from ilqr_amd.ilqr_boxQP import boxQP
     g = np.load(golden_dir + "/ref_boxqp.npz")
