@@ -9,6 +9,6 @@ __version__ = "0.1.0"
 
 from .ilqr_core import iLQR, RecedingHorizonController  # noqa: E402,F401
 from .ilqr_dynamics import Dynamics  # noqa: E402,F401
-from .ilqr_cost import Cost, QRCost  # noqa: E402,F401
+from .ilqr_cost import Cost, PathQRCost, QRCost  # noqa: E402,F401
 
-__all__ = ["iLQR", "RecedingHorizonController", "Dynamics", "Cost", "QRCost"]
+__all__ = ["iLQR", "RecedingHorizonController", "Dynamics", "Cost", "QRCost", "PathQRCost"]

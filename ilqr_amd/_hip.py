@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libilqr_hip.so")
 
 ILQR_OK = 0
 MODEL_CARTPOLE = 0
-COST_QR = 0
+COST_QR, COST_PATH_QR = 0, 1
 STATUS_RAN_OUT, STATUS_CONVERGED, STATUS_MU_MAX = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
@@ -97,7 +97,10 @@ class Model:
     """Host description of the problem family (model + cost + bounds)."""
 
     def __init__(self, T, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
-                 dt=0.05, mc=1.0, mp=0.1, l=1.0, g=9.8, n=5, m=1, model=MODEL_CARTPOLE, control_limit=True):
+                 dt=0.05, mc=1.0, mp=0.1, l=1.0, g=9.8, n=5, m=1, model=MODEL_CARTPOLE, control_limit=True,
+                 x_path=None, u_path=None):
+        """QRCost: x_goal [n], u_goal [m] (host).  PathQRCost: x_path [T+1, n], u_path [T, m] as
+        fp64 device tensors (kept alive by this object); x_goal / u_goal are then ignored."""
         self.n, self.m, self.T = int(n), int(m), int(T)
         self.Q = _host(Q, (n, n))
         self.R = _host(R, (m, m))
@@ -113,6 +116,17 @@ class Model:
         for name, arr in (("Q", self.Q), ("R", self.R), ("Q_terminal", self.Qt), ("x_goal", self.x_goal),
                           ("u_goal", self.u_goal), ("lower", self.lower), ("upper", self.upper)):
             setattr(c, name, arr.ctypes.data_as(_dp))
+        if x_path is not None:
+            import torch
+            if u_path is None:
+                raise ValueError("PathQRCost needs both x_path and u_path")
+            self.x_path = _req(x_path, torch.float64)
+            self.u_path = _req(u_path, torch.float64)
+            if tuple(self.x_path.shape) != (T + 1, n) or tuple(self.u_path.shape) != (T, m):
+                raise ValueError("x_path must be [%d, %d] and u_path [%d, %d]" % (T + 1, n, T, m))
+            c.cost_kind = COST_PATH_QR
+            c.x_goal = C.cast(C.c_void_p(self.x_path.data_ptr()), _dp)
+            c.u_goal = C.cast(C.c_void_p(self.u_path.data_ptr()), _dp)
         self.c = c
 
 

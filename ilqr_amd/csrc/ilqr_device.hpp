@@ -52,6 +52,10 @@ struct QRCostP {      // QRCost, ilqr/ilqr_cost.py:490-530, m = 1
     double QQt[25];   // Q_terminal + Q_terminal^T (:528)
     double R, RR;     // R, R + R^T         (:527)
     double xg[5], ug; // x_goal, u_goal
+    // PathQRCost (ilqr/ilqr_cost.py:635-770): goals indexed by the time step, shared by the
+    // batch; device arrays [(T+1)*5] and [T], null for QRCost
+    const double* x_path;
+    const double* u_path;
 };
 
 struct QPOptsP { // ilqr_core.py:154-155
@@ -211,6 +215,7 @@ __device__ __forceinline__ void cartpole_jac(const CartpoleC& P, const double (&
 //   lxx(a, b), lxx_terminal(a, b) :589-601
 //   add_lxx(a, b, v) = lxx(a, b) + v
 //   luu()                         :617-632
+//   at(i), at_terminal(N)         select the time step (only PathQR depends on it)
 //
 // DenseQR reads the full matrices from the kernel arguments.  DiagQR is used when
 // Q and Q_terminal are diagonal (the host checks): it keeps the ten diagonal
@@ -219,6 +224,8 @@ __device__ __forceinline__ void cartpole_jac(const CartpoleC& P, const double (&
 struct DenseQR {
     const QRCostP& C;
     __device__ __forceinline__ explicit DenseQR(const QRCostP& c) : C(c) {}
+    __device__ __forceinline__ void at(int) const {}          // the goal does not depend on the step
+    __device__ __forceinline__ void at_terminal(int) const {}
 
     __device__ __forceinline__ double quad(const double (&v)[NX], const double* M) const
     {
@@ -296,6 +303,8 @@ struct DiagQR {
         RR = vreg(C.RR);
         ug = vreg(C.ug);
     }
+    __device__ __forceinline__ void at(int) const {}
+    __device__ __forceinline__ void at_terminal(int) const {}
     __device__ __forceinline__ double quad(const double (&v)[NX], const double (&d)[NX]) const
     {
         // the dense chain with every off-diagonal product dropped: column j of
@@ -344,6 +353,91 @@ struct DiagQR {
     __device__ __forceinline__ double lxx_terminal(int a, int b) const { return a == b ? qqt[a] : 0.0; }
     __device__ __forceinline__ double add_lxx(int a, int b, double v) const { return a == b ? qq[a] + v : v; }
     __device__ __forceinline__ double luu() const { return RR; }
+};
+
+
+// PathQRCost (ilqr/ilqr_cost.py:635-770): the goals are x_path[i], u_path[i], and the value
+// has NO 1/2 (:695, :701) while the gradients and Hessians are those of QRCost.  at(i) /
+// at_terminal(N) select the step before any evaluation (uniform loads: the path is shared
+// by all problems of the batch).
+struct PathQR {
+    const QRCostP& C;
+    mutable double xg[NX], ug;
+    __device__ __forceinline__ explicit PathQR(const QRCostP& c) : C(c)
+    {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xg[i] = 0.0;
+        ug = 0.0;
+    }
+    __device__ __forceinline__ void at(int t) const
+    {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xg[i] = C.x_path[t * NX + i];
+        ug = C.u_path[t];
+    }
+    __device__ __forceinline__ void at_terminal(int T) const
+    {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xg[i] = C.x_path[T * NX + i];
+    }
+    __device__ __forceinline__ double quad(const double (&v)[NX], const double* M) const
+    {
+        double tot = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            double acc = v[0] * M[j];
+#pragma unroll
+            for (int i = 1; i < NX; ++i)
+                acc = fma(v[i], M[i * NX + j], acc);
+            tot = (j == 0) ? acc * v[0] : fma(acc, v[j], tot);
+        }
+        return tot;
+    }
+    __device__ __forceinline__ void diff(const double (&x)[NX], double (&xd)[NX]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            xd[i] = x[i] - xg[i];
+    }
+    __device__ __forceinline__ double l(const double (&x)[NX], double u) const
+    {
+        double xd[NX];
+        diff(x, xd);
+        double ud = u - ug;
+        return quad(xd, C.Q) + (ud * C.R) * ud;
+    }
+    __device__ __forceinline__ double l_terminal(const double (&x)[NX]) const
+    {
+        double xd[NX];
+        diff(x, xd);
+        return quad(xd, C.Qt);
+    }
+    __device__ __forceinline__ void lx_with(const double* QQ, const double (&x)[NX], double (&out)[NX]) const
+    {
+        double xd[NX];
+        diff(x, xd);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            double acc = xd[0] * QQ[j];
+#pragma unroll
+            for (int a = 1; a < NX; ++a)
+                acc = fma(xd[a], QQ[a * NX + j], acc);
+            out[j] = acc;
+        }
+    }
+    __device__ __forceinline__ void lx(const double (&x)[NX], double (&out)[NX]) const { lx_with(C.QQ, x, out); }
+    __device__ __forceinline__ void lx_terminal(const double (&x)[NX], double (&out)[NX]) const
+    {
+        lx_with(C.QQt, x, out);
+    }
+    __device__ __forceinline__ double lu(double u) const { return (u - ug) * C.RR; }
+    __device__ __forceinline__ double lxx(int a, int b) const { return C.QQ[a * NX + b]; }
+    __device__ __forceinline__ double lxx_terminal(int a, int b) const { return C.QQt[a * NX + b]; }
+    __device__ __forceinline__ double add_lxx(int a, int b, double v) const { return C.QQ[a * NX + b] + v; }
+    __device__ __forceinline__ double luu() const { return C.RR; }
 };
 
 // ---- boxQP, m = 1 -------------------------------------------------------------

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP Cp,
     for (int t = 0; t < T; ++t) {
         double u = us[(int64_t)t * ld + b];
         store5(xs, ld, (int64_t)t * NX, b, x);
+        C.at(t);
         J = J + C.l(x, u);
         cartpole_f(P, x, u, xn);
 #pragma unroll
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP Cp,
             x[i] = xn[i];
     }
     store5(xs, ld, (int64_t)T * NX, b, x);
+    C.at_terminal(T);
     Jout[b] = J + C.l_terminal(x);
 }
 
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP Cp,
 
 // One thread per (problem, step): f_x, f_u, l_x, l_u, l_xx, l_uu, l_ux as dense
 // batch-minor streams (what _compute_Q_terms asks the model for, ilqr_core.py:189-198).
+template <class Cost>
 __global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP Cp, int T, int64_t B, int64_t ld,
                                                const double* __restrict__ xs,
                                                const double* __restrict__ us, ilqr_deriv_bm_t o)
@@ -157,11 +160,12 @@ __global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP Cp, int T, 
     if (b >= B)
         return;
     CartpoleC P = cartpole_consts(mp);
-    DenseQR C(Cp);
+    Cost C(Cp);
     double x[NX];
     load5(xs, ld, (int64_t)t * NX, b, x);
     if (t == T) { // terminal l_x, l_xx (ilqr_core.py:120-121)
         double lx[NX];
+        C.at_terminal(T);
         C.lx_terminal(x, lx);
         store5(o.lxT, ld, 0, b, lx);
         for (int i = 0; i < NX * NX; ++i)
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP Cp, int T, 
     }
     double fu[NX] = {0.0, J.b1, 0.0, 0.0, J.b4};
     double lx[NX], zero[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    C.at(t);
     C.lx(x, lx);
     store5(o.fu, ld, (int64_t)t * NX, b, fu);
     store5(o.lx, ld, (int64_t)t * NX, b, lx);
@@ -223,6 +228,7 @@ __device__ __forceinline__ int backward_sweep(const CartpoleC& P, const Cost& C,
 {
     double xnext[NX];
     load5(xs, ld, (int64_t)T * NX, b, xnext);
+    C.at_terminal(T);
     bw_init(C, xnext, S);
     stopped_at = -1;
     double x[NX], u;
@@ -267,6 +273,7 @@ __device__ __forceinline__ int backward_sweep(const CartpoleC& P, const Cost& C,
             }
             CartpoleJac J;
             cartpole_jac(P, x, u, sn, cn, J);
+            C.at(i);
             double kt, Kt[NX];
             int qr;
             bool qf;
@@ -379,6 +386,7 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost
             us_new[(int64_t)ts * ld + b] = pend_u;
         }
         double un = fw_control(xn, xo, u, kk, Kr, alpha);
+        C.at(t);
         J = J + C.l(xn, un);
         cartpole_f(P, xn, un, xt);
         if (STORE) {
@@ -403,6 +411,7 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost
         us_new[(int64_t)(T - 1) * ld + b] = pend_u;
         store5(xs_new, ld, (int64_t)T * NX, b, xn);
     }
+    C.at_terminal(T);
     return J + C.l_terminal(xn);
 }
 
@@ -532,6 +541,7 @@ __global__ __launch_bounds__(256, OCC) void k_solve(CartpoleP mp, QRCostP Cp, So
             double u = us0[(int64_t)t * ld + b];
             if (t > 0)
                 store5(xs0, ld, (int64_t)t * NX, b, x);
+            C.at(t);
             J = J + C.l(x, u);
             cartpole_f(P, x, u, xn);
 #pragma unroll
@@ -539,6 +549,7 @@ __global__ __launch_bounds__(256, OCC) void k_solve(CartpoleP mp, QRCostP Cp, So
                 x[i] = xn[i];
         }
         store5(xs0, ld, (int64_t)T * NX, b, x);
+        C.at_terminal(T);
         J = J + C.l_terminal(x);
     }
 
@@ -1003,10 +1014,11 @@ int check_model(const ilqr_model* m)
 {
     if (!m)
         return ILQR_ERR_ARG;
-    if (m->model != ILQR_MODEL_CARTPOLE || m->n != 5 || m->m != 1 || m->cost_kind != ILQR_COST_QR ||
-        m->control_limit != 1)
+    if (m->model != ILQR_MODEL_CARTPOLE || m->n != 5 || m->m != 1 || (m->cost_kind != ILQR_COST_QR && m->cost_kind != ILQR_COST_PATH_QR) || m->control_limit != 1)
         return ILQR_ERR_UNSUPPORTED;
     if (m->T < 1 || !m->Q || !m->R || !m->lower || !m->upper)
+        return ILQR_ERR_ARG;
+    if (m->cost_kind == ILQR_COST_PATH_QR && (!m->x_goal || !m->u_goal)) // the paths are mandatory
         return ILQR_ERR_ARG;
     return ILQR_OK;
 }
@@ -1028,9 +1040,19 @@ void fill_model(const ilqr_model* m, CartpoleP& mp, QRCostP& C, BoundsP& bd)
         }
     C.R = m->R[0];
     C.RR = m->R[0] + m->R[0];
-    for (int a = 0; a < 5; ++a)
-        C.xg[a] = m->x_goal ? m->x_goal[a] : 0.0;
-    C.ug = m->u_goal ? m->u_goal[0] : 0.0;
+    if (m->cost_kind == ILQR_COST_PATH_QR) { // device arrays, read by the kernels
+        for (int a = 0; a < 5; ++a)
+            C.xg[a] = 0.0;
+        C.ug = 0.0;
+        C.x_path = m->x_goal;
+        C.u_path = m->u_goal;
+    } else {
+        for (int a = 0; a < 5; ++a)
+            C.xg[a] = m->x_goal ? m->x_goal[a] : 0.0;
+        C.ug = m->u_goal ? m->u_goal[0] : 0.0;
+        C.x_path = nullptr;
+        C.u_path = nullptr;
+    }
     bd.lo = m->lower[0];
     bd.hi = m->upper[0];
 }
@@ -1052,6 +1074,15 @@ bool use_diag(const QRCostP& C)
     if (e && e[0] == '1')
         return false;
     return cost_is_diagonal(C);
+}
+
+// Which cost evaluator a launch instantiates.
+enum { EVAL_DIAG = 0, EVAL_DENSE = 1, EVAL_PATH = 2 };
+int cost_eval(const QRCostP& C)
+{
+    if (C.x_path != nullptr)
+        return EVAL_PATH;
+    return use_diag(C) ? EVAL_DIAG : EVAL_DENSE;
 }
 
 int fill_qp(const ilqr_opts* o, QPOptsP& q)
@@ -1150,12 +1181,15 @@ int ilqr_rollout_cost_bm(const ilqr_model* model, int64_t B, int64_t ld, const d
     QRCostP C;
     BoundsP bd;
     fill_model(model, mp, C, bd);
-    if (use_diag(C))
-        hipLaunchKernelGGL(k_rollout_cost<DiagQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
-                           as_stream(stream), mp, C, model->T, B, ld, x0, us, xs, J);
-    else
-        hipLaunchKernelGGL(k_rollout_cost<DenseQR>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,
-                           as_stream(stream), mp, C, model->T, B, ld, x0, us, xs, J);
+#define ILQR_LAUNCH_RC(COST)                                                                              \
+    hipLaunchKernelGGL(k_rollout_cost<COST>, dim3((unsigned)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0,         \
+                       as_stream(stream), mp, C, model->T, B, ld, x0, us, xs, J)
+    switch (cost_eval(C)) {
+    case EVAL_DIAG: ILQR_LAUNCH_RC(DiagQR); break;
+    case EVAL_DENSE: ILQR_LAUNCH_RC(DenseQR); break;
+    default: ILQR_LAUNCH_RC(PathQR); break;
+    }
+#undef ILQR_LAUNCH_RC
     return hip_status(hipGetLastError());
 }
 
@@ -1172,8 +1206,12 @@ int ilqr_deriv_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* 
     QRCostP C;
     BoundsP bd;
     fill_model(model, mp, C, bd);
-    hipLaunchKernelGGL(k_deriv, dim3((unsigned)((B + 255) / 256), (unsigned)(model->T + 1)), dim3(256), 0,
-                       as_stream(stream), mp, C, model->T, B, ld, xs, us, *out);
+    if (C.x_path != nullptr)
+        hipLaunchKernelGGL(k_deriv<PathQR>, dim3((unsigned)((B + 255) / 256), (unsigned)(model->T + 1)), dim3(256),
+                           0, as_stream(stream), mp, C, model->T, B, ld, xs, us, *out);
+    else
+        hipLaunchKernelGGL(k_deriv<DenseQR>, dim3((unsigned)((B + 255) / 256), (unsigned)(model->T + 1)), dim3(256),
+                           0, as_stream(stream), mp, C, model->T, B, ld, xs, us, *out);
     return hip_status(hipGetLastError());
 }
 
@@ -1200,18 +1238,23 @@ int ilqr_backward_bm(const ilqr_model* model, const ilqr_opts* opts, int64_t B, 
     if ((qp_result_bm == nullptr) != (free_bm == nullptr))
         return ILQR_ERR_ARG;
     dim3 grid((unsigned)((B + WAVE - 1) / WAVE));
-    bool rec = qp_result_bm != nullptr, diag = use_diag(C);
+    bool rec = qp_result_bm != nullptr;
+    int ev = cost_eval(C);
 #define ILQR_LAUNCH_BW(COST, REC)                                                                            \
     hipLaunchKernelGGL((k_backward<COST, REC>), grid, dim3(WAVE), 0, as_stream(stream), mp, C, q, bd, model->T, \
                        B, ld, xs, us, mu, k, K, dJ, info, qp_result_bm, free_bm)
-    if (diag && rec)
+    if (ev == EVAL_DIAG && rec)
         ILQR_LAUNCH_BW(DiagQR, true);
-    else if (diag)
+    else if (ev == EVAL_DIAG)
         ILQR_LAUNCH_BW(DiagQR, false);
-    else if (rec)
+    else if (ev == EVAL_DENSE && rec)
         ILQR_LAUNCH_BW(DenseQR, true);
-    else
+    else if (ev == EVAL_DENSE)
         ILQR_LAUNCH_BW(DenseQR, false);
+    else if (rec)
+        ILQR_LAUNCH_BW(PathQR, true);
+    else
+        ILQR_LAUNCH_BW(PathQR, false);
 #undef ILQR_LAUNCH_BW
     return hip_status(hipGetLastError());
 }
@@ -1234,18 +1277,23 @@ int ilqr_forward_ls_bm(const ilqr_model* model, int64_t B, int64_t ld, int32_t n
     for (int i = 0; i < 32; ++i)
         al.a[i] = i < n_alpha ? alphas[i] : 0.0;
     dim3 grid((unsigned)((B + WAVE - 1) / WAVE), (unsigned)n_alpha);
-    bool st = xs_new != nullptr, diag = use_diag(C);
+    bool st = xs_new != nullptr;
+    int ev = cost_eval(C);
 #define ILQR_LAUNCH_FW(COST, ST)                                                                              \
     hipLaunchKernelGGL((k_forward_ls<COST, ST>), grid, dim3(WAVE), 0, as_stream(stream), mp, C, al, model->T, B, \
                        ld, xs, us, k, K, J_new, xs_new, us_new)
-    if (diag && st)
+    if (ev == EVAL_DIAG && st)
         ILQR_LAUNCH_FW(DiagQR, true);
-    else if (diag)
+    else if (ev == EVAL_DIAG)
         ILQR_LAUNCH_FW(DiagQR, false);
-    else if (st)
+    else if (ev == EVAL_DENSE && st)
         ILQR_LAUNCH_FW(DenseQR, true);
-    else
+    else if (ev == EVAL_DENSE)
         ILQR_LAUNCH_FW(DenseQR, false);
+    else if (st)
+        ILQR_LAUNCH_FW(PathQR, true);
+    else
+        ILQR_LAUNCH_FW(PathQR, false);
 #undef ILQR_LAUNCH_FW
     return hip_status(hipGetLastError());
 }
@@ -1314,18 +1362,22 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
     int occ = B > 64 * 1024 ? 2 : 1; // more than one wave per SIMD to place?
     if (const char* e = std::getenv("ILQR_SOLVE_OCC"))
         occ = std::atoi(e) == 2 ? 2 : 1;
-    bool diag = use_diag(C);
+    int ev = cost_eval(C);
 #define ILQR_LAUNCH_SOLVE(COST, OCC)                                                                          \
     hipLaunchKernelGGL((k_solve<COST, OCC>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, \
                        iters, status, tr)
-    if (diag && occ == 1)
+    if (ev == EVAL_DIAG && occ == 1)
         ILQR_LAUNCH_SOLVE(DiagQR, 1);
-    else if (diag)
+    else if (ev == EVAL_DIAG)
         ILQR_LAUNCH_SOLVE(DiagQR, 2);
-    else if (occ == 1)
+    else if (ev == EVAL_DENSE && occ == 1)
         ILQR_LAUNCH_SOLVE(DenseQR, 1);
-    else
+    else if (ev == EVAL_DENSE)
         ILQR_LAUNCH_SOLVE(DenseQR, 2);
+    else if (occ == 1)
+        ILQR_LAUNCH_SOLVE(PathQR, 1);
+    else
+        ILQR_LAUNCH_SOLVE(PathQR, 2);
 #undef ILQR_LAUNCH_SOLVE
     hipLaunchKernelGGL(k_unpack, tile_grid(B, (T + 1) * 5), dim3(256), 0, st, (const double*)W.xs[0],
                        (const double*)W.xs[1], (const int32_t*)W.sel_traj, xs, B, (T + 1) * 5, tiled);

@@ -14,7 +14,7 @@ import warnings
 import numpy as np
 
 from . import _hip
-from .ilqr_cost import QRCost
+from .ilqr_cost import PathQRCost, QRCost
 
 
 class BaseTrajOptimizer(abc.ABC):
@@ -45,8 +45,11 @@ class iLQR(BaseTrajOptimizer):
                 "iLQR on the GPU needs a dynamics model with a device implementation "
                 "(ilqr_amd.cartpole.CartPoleDynamics); %r evaluates through Python callbacks, which cannot "
                 "run inside a kernel" % type(sys_dynamics).__name__)
-        if not isinstance(cost_func, QRCost):
-            raise NotImplementedError("only QRCost has a device implementation")
+        if not isinstance(cost_func, (QRCost, PathQRCost)):
+            raise NotImplementedError("only QRCost and PathQRCost have a device implementation")
+        if isinstance(cost_func, PathQRCost) and cost_func.x_path.shape[0] != int(time_steps) + 1:
+            raise ValueError("x_path holds %d states, the horizon needs %d" % (cost_func.x_path.shape[0],
+                                                                             int(time_steps) + 1))
         if control_limit is not True:
             # In the reference this branch keeps the positive-sign warm-start gains, predicts a
             # cost INCREASE and rejects every iteration (ilqr_core.py:145,162,305-308).
@@ -79,8 +82,12 @@ class iLQR(BaseTrajOptimizer):
     # ------------------------------------------------------------------ helpers
     def _model(self):
         d, c = self.dynamics, self.cost
-        return _hip.Model(self.N, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal, self.lower_bound, self.upper_bound,
-                          dt=d.tau, mc=d.masscart, mp=d.masspole, l=d.length, g=d.gravity)
+        kw = dict(dt=d.tau, mc=d.masscart, mp=d.masspole, l=d.length, g=d.gravity)
+        if isinstance(c, PathQRCost):
+            x_path, u_path = c.device_paths(self._device())
+            return _hip.Model(self.N, c.Q, c.R, c.Q_terminal, None, None, self.lower_bound, self.upper_bound,
+                              x_path=x_path, u_path=u_path, **kw)
+        return _hip.Model(self.N, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal, self.lower_bound, self.upper_bound, **kw)
 
     def _device(self):
         import torch

@@ -92,3 +92,81 @@ class QRCost(Cost):
         if terminal:
             return np.zeros_like(self.R)
         return self._R_plus_R_T
+
+
+class PathQRCost(Cost):
+    """Quadratic Regulator Instantaneous Cost for trajectory following
+    (ilqr/ilqr_cost.py:635-770): goals x_path[i], u_path[i] indexed by the time step.
+
+    As in the reference the VALUE has no factor 1/2 here (l = x'Qx + u'Ru, :695-701)
+    while the derivatives are those of QRCost (l_x = x'(Q+Q'), ...).  One path is
+    shared by every problem of a batch.
+
+    ``u_path=None``: the reference crashes there (``np.zeros(path_length - 1,
+    action_size)``, :663, is a TypeError); the zeros it meant to build are used."""
+
+    def __init__(self, Q, R, x_path, u_path=None, Q_terminal=None):
+        self.Q = np.array(Q, dtype=np.float64)
+        self.R = np.array(R, dtype=np.float64)
+        self.x_path = np.array(x_path, dtype=np.float64)
+
+        state_size = self.Q.shape[0]
+        action_size = self.R.shape[0]
+        path_length = self.x_path.shape[0]
+
+        self.Q_terminal = self.Q if Q_terminal is None else np.array(Q_terminal, dtype=np.float64)
+        if u_path is None:
+            self.u_path = np.zeros((path_length - 1, action_size))
+        else:
+            self.u_path = np.array(u_path, dtype=np.float64)
+
+        assert self.Q.shape == self.Q_terminal.shape, "Q & Q_terminal mismatch"
+        assert self.Q.shape[0] == self.Q.shape[1], "Q must be square"
+        assert self.R.shape[0] == self.R.shape[1], "R must be square"
+        assert state_size == self.x_path.shape[1], "Q & x_path mismatch"
+        assert action_size == self.u_path.shape[1], "R & u_path mismatch"
+        assert path_length == self.u_path.shape[0] + 1, "x_path must be 1 longer than u_path"
+
+        self._Q_plus_Q_T = self.Q + self.Q.T
+        self._R_plus_R_T = self.R + self.R.T
+        self._Q_plus_Q_T_terminal = self.Q_terminal + self.Q_terminal.T
+        self._device_paths = {}
+        super().__init__()
+
+    def device_paths(self, device):
+        """x_path, u_path as fp64 tensors on ``device`` (uploaded once per device)."""
+        import torch
+        key = str(device)
+        if key not in self._device_paths:
+            self._device_paths[key] = (torch.tensor(self.x_path, device=device).contiguous(),
+                                       torch.tensor(self.u_path, device=device).contiguous())
+        return self._device_paths[key]
+
+    def l(self, x, u, i, terminal=False):
+        Q = self.Q_terminal if terminal else self.Q
+        x_diff = x - self.x_path[i]
+        squared_x_cost = x_diff.T.dot(Q).dot(x_diff)
+        if terminal:
+            return squared_x_cost
+        u_diff = u - self.u_path[i]
+        return squared_x_cost + u_diff.T.dot(self.R).dot(u_diff)
+
+    def l_x(self, x, u, i, terminal=False):
+        Q_plus_Q_T = self._Q_plus_Q_T_terminal if terminal else self._Q_plus_Q_T
+        return (x - self.x_path[i]).T.dot(Q_plus_Q_T)
+
+    def l_u(self, x, u, i, terminal=False):
+        if terminal:
+            return np.zeros_like(self.u_path)
+        return (u - self.u_path[i]).T.dot(self._R_plus_R_T)
+
+    def l_xx(self, x, u, i, terminal=False):
+        return self._Q_plus_Q_T_terminal if terminal else self._Q_plus_Q_T
+
+    def l_ux(self, x, u, i, terminal=False):
+        return np.zeros((self.R.shape[0], self.Q.shape[0]))
+
+    def l_uu(self, x, u, i, terminal=False):
+        if terminal:
+            return np.zeros_like(self.R)
+        return self._R_plus_R_T

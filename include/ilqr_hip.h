@@ -36,7 +36,7 @@ typedef enum ilqr_status {
 } ilqr_status;
 
 enum { ILQR_MODEL_CARTPOLE = 0 };
-enum { ILQR_COST_QR = 0 };
+enum { ILQR_COST_QR = 0, ILQR_COST_PATH_QR = 1 };
 
 /* Per-problem status written by ilqr_solve_batched (update_u's three exits,
  * ilqr_core.py:284, :331/:347, :337-339). */
@@ -47,7 +47,11 @@ enum { ILQR_RAN_OUT = 0, ILQR_CONVERGED = 1, ILQR_MU_MAX = 2 };
  * arguments by each call.
  *   cartpole: CartPoleDynamics(dt, max_control, mc, mp, l, g), ilqr/cartpole.py:8;
  *             n = 5 ([x, x', sin, cos, theta']), m = 1.
- *   QRCost(Q, R, Q_terminal, x_goal, u_goal), ilqr/ilqr_cost.py:490-530. */
+ *   QRCost(Q, R, Q_terminal, x_goal, u_goal), ilqr/ilqr_cost.py:490-530.
+ *   PathQRCost(Q, R, x_path, u_path, Q_terminal), ilqr/ilqr_cost.py:639-680
+ *   (cost_kind = ILQR_COST_PATH_QR): time-indexed goals shared by the batch; the
+ *   one exception to the host-pointer rule: x_goal / u_goal then point to DEVICE
+ *   arrays x_path [(T+1)*n] and u_path [T*m] (both required), read by the kernels. */
 typedef struct ilqr_model {
     int32_t model;         /* ILQR_MODEL_* */
     int32_t n, m, T;       /* state dim, control dim, horizon N */
@@ -55,7 +59,7 @@ typedef struct ilqr_model {
     int32_t control_limit; /* iLQR(control_limit=...), ilqr_core.py:32; only 1 is supported */
     double dt, mc, mp, l, g;
     const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] row-major */
-    const double *x_goal, *u_goal;    /* [n], [m] */
+    const double *x_goal, *u_goal;    /* QR: host [n], [m] (NULL = zeros); PATH_QR: device [(T+1)*n], [T*m] */
     const double *lower, *upper;      /* dynamics.lower_bound / upper_bound, [m] */
 } ilqr_model;
 

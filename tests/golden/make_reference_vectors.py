@@ -343,9 +343,52 @@ def make_mpc_vectors(mods):
     print("mpc final state", states[-1])
 
 
+def pathqr_problem(N=60):
+    """A trajectory-following problem for PathQRCost (ilqr_cost.py:635-770): track a smooth
+    swing from hanging to upright while the cart moves out and back."""
+    t = np.linspace(0.0, 1.0, N + 1)
+    theta = np.pi * (1.0 - t) ** 2
+    st = np.stack([0.4 * np.sin(np.pi * t), 0.4 * np.pi * np.cos(np.pi * t) / (N * 0.05),
+                   theta, np.gradient(theta, 0.05 * N / N)], axis=1)
+    x_path = augment(st)
+    u_path = 0.5 * np.cos(3.0 * np.pi * t[:-1]).reshape(N, 1)
+    Q = np.diag([20.0, 2.0, 50.0, 50.0, 5.0])
+    Q[0, 1] = 1.5                      # a non-symmetric Q: l_x uses Q + Q^T, l uses Q
+    R = np.array([[0.8]])
+    Qt = 80.0 * np.eye(5)
+    return x_path, u_path, Q, R, Qt
+
+
+def make_pathqr_vectors(mods):
+    """update_u of the reference with its PathQRCost, dynamics from the oracle (libm mode)."""
+    N = 60
+    x_path, u_path, Q, R, Qt = pathqr_problem(N)
+    cost = mods["ilqr_cost"].PathQRCost(Q, R, x_path, u_path, Q_terminal=Qt)
+    dyn = OracleCartPole(0.05)
+    rs = np.random.RandomState(23)
+    store = dict(N=N, x_path=x_path, u_path=u_path, Q=Q, R=R, Qt=Qt)
+    for i in range(3):
+        st = np.array([rs.uniform(-0.3, 0.3), rs.uniform(-0.3, 0.3), np.pi + rs.uniform(-0.4, 0.4),
+                       rs.uniform(-0.5, 0.5)])
+        us = rs.uniform(-1, 1, (N, 1))
+        out = run_update_u(mods, dyn, cost, N, augment(st), us, n_interations=50)
+        out["max_iter"] = 50
+        # single calls of the cost itself
+        out["l0"] = cost.l(out["xs"][3], out["us"][3], 3)
+        out["lT"] = cost.l(out["xs"][N], None, N, terminal=True)
+        out["lx0"] = cost.l_x(out["xs"][3], out["us"][3], 3)
+        out["lu0"] = cost.l_u(out["xs"][3], out["us"][3], 3)
+        pack("p%d_" % i, out, store)
+        print("pathqr", i, "iters", len(out["it_J"]), "J", out["it_J"][-1], "conv", out["it_converged"][-1])
+    store["n_problems"] = 3
+    np.savez_compressed(os.path.join(HERE, "ref_pathqr_solve.npz"), **store)
+
+
 if __name__ == "__main__":
     mods = load_reference()
-    which = sys.argv[1:] or ["boxqp", "stages", "solve", "mpc"]
+    which = sys.argv[1:] or ["boxqp", "stages", "solve", "mpc", "pathqr"]
+    if "pathqr" in which:
+        make_pathqr_vectors(mods)
     if "boxqp" in which:
         make_boxqp_vectors(mods)
     if "stages" in which:

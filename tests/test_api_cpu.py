@@ -11,7 +11,7 @@ import ilqr_amd
 from ilqr_amd import _hip
 from ilqr_amd.cartpole import CartPoleDynamics
 from ilqr_amd.ilqr_core import RecedingHorizonController, iLQR
-from ilqr_amd.ilqr_cost import Cost, QRCost
+from ilqr_amd.ilqr_cost import Cost, PathQRCost, QRCost
 from ilqr_amd.ilqr_dynamics import Dynamics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -130,6 +130,29 @@ def test_qrcost_host_formulas(golden_dir):
     assert not c.l_uu(x, u, 0, terminal=True).any() and not c.l_u(x, u, 0, terminal=True).any()
     with pytest.raises(AssertionError):
         QRCost(np.eye(5), np.eye(1), Q_terminal=np.eye(4))
+
+
+def test_pathqrcost_host_formulas_against_reference_values(golden_dir):
+    """PathQRCost: time-indexed goals, value WITHOUT the 1/2 (ilqr_cost.py:695-701); numbers
+    returned by the reference's own class are in the fixture."""
+    g = np.load(golden_dir + "/ref_pathqr_solve.npz")
+    N = int(g["N"])
+    c = PathQRCost(g["Q"], g["R"], g["x_path"], g["u_path"], Q_terminal=g["Qt"])
+    for i in range(int(g["n_problems"])):
+        p = "p%d_" % i
+        xs, us = g[p + "xs"], g[p + "us"]
+        np.testing.assert_allclose(c.l(xs[3], us[3], 3), g[p + "l0"], rtol=1e-13)
+        np.testing.assert_allclose(c.l(xs[N], None, N, terminal=True), g[p + "lT"], rtol=1e-13)
+        np.testing.assert_allclose(c.l_x(xs[3], us[3], 3), g[p + "lx0"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(c.l_u(xs[3], us[3], 3), g[p + "lu0"], rtol=1e-13, atol=1e-13)
+    xd = xs[3] - g["x_path"][3]
+    assert np.isclose(c.l(xs[3], us[3], 3), xd @ g["Q"] @ xd + (us[3] - g["u_path"][3]) @ g["R"] @ (us[3] - g["u_path"][3]))
+    assert np.array_equal(c.l_xx(xs[0], us[0], 0), g["Q"] + g["Q"].T) and not c.l_ux(xs[0], us[0], 0).any()
+    # u_path=None: zeros (the reference raises TypeError at ilqr_cost.py:663)
+    z = PathQRCost(g["Q"], g["R"], g["x_path"])
+    assert z.u_path.shape == (N, 1) and not z.u_path.any()
+    with pytest.raises(AssertionError):
+        PathQRCost(g["Q"], g["R"], g["x_path"], g["u_path"][:-1])
 
 
 def test_receding_horizon_shift_logic():

@@ -195,6 +195,31 @@ def test_mpc_full_size_closed_loops_on_device():
         n_it = 10
 
 
+def test_pathqrcost_through_the_solver_api(golden_dir):
+    """iLQR(dynamics, PathQRCost(...)) as a user of the reference would write it; single problem
+    against the recorded reference run, batch against the oracle."""
+    from ilqr_amd import PathQRCost, iLQR
+    from ilqr_amd.cartpole import CartPoleDynamics
+    g = np.load(golden_dir + "/ref_pathqr_solve.npz")
+    N = int(g["N"])
+    dyn = CartPoleDynamics(0.05)
+    cost = PathQRCost(g["Q"], g["R"], g["x_path"], g["u_path"], Q_terminal=g["Qt"])
+    s = iLQR(dyn, cost, N)
+    xs, us = s.update_u(g["p2_x0"], g["p2_us_init"], n_interations=int(g["p2_max_iter"]))
+    assert s.iterations_ == len(g["p2_it_J"]) and s.status_ == 1
+    np.testing.assert_allclose(s.J_, g["p2_it_J"][-1], rtol=1e-9)
+    np.testing.assert_allclose(us, g["p2_us"], rtol=0, atol=1e-8)
+    Mo = co.Model(co.MODEL_CARTPOLE, 5, 1, N, co.COST_PATHQR, co.MATH_DET, True, dt=0.05, Q=g["Q"], R=g["R"],
+                  Q_terminal=g["Qt"], x_goal=g["x_path"], u_goal=g["u_path"], lower=[-5.0], upper=[5.0])
+    B = 70
+    x0, us0 = co.cartpole_batch(B, T=N, seed_x=91, seed_u=92)
+    ref = co.solve(Mo, co.Opts(max_iter=25), x0, us0, nthreads=8, trace=False)
+    xs_b, us_b = iLQR(dyn, cost, N).update_u(x0, us0, n_iterations=25)
+    assert eq(xs_b, ref["xs"]) and eq(us_b, ref["us"])
+    with pytest.raises(ValueError):
+        iLQR(dyn, cost, N + 1)  # the path is too short for this horizon
+
+
 def test_boxqp_api(golden_dir):
     from ilqr_amd.ilqr_boxQP import boxQP
     g = np.load(golden_dir + "/ref_boxqp.npz")

@@ -292,6 +292,70 @@ def test_boxqp1_shortcuts_over_magnitudes(hip, step_dec, armijo, min_step):
     assert len(set(ref["result"].tolist())) >= 3
 
 
+def pathqr_models(hip, golden_dir, T=None):
+    g = np.load(golden_dir + "/ref_pathqr_solve.npz")
+    N = int(g["N"]) if T is None else T
+    xp, up = g["x_path"][:N + 1], g["u_path"][:N]
+    Mo = co.Model(co.MODEL_CARTPOLE, 5, 1, N, co.COST_PATHQR, co.MATH_DET, True, dt=0.05, Q=g["Q"], R=g["R"],
+                  Q_terminal=g["Qt"], x_goal=xp, u_goal=up, lower=[-5.0], upper=[5.0])
+    M = hip.Model(N, g["Q"], g["R"], g["Qt"], None, None, [-5.0], [5.0], dt=0.05, x_path=dev(xp), u_path=dev(up))
+    return g, Mo, M
+
+
+def test_pathqr_stages_bit_exact(hip, golden_dir):
+    """PathQRCost (time-indexed goals, value without the 1/2, non-symmetric Q) through every
+    stage kernel against the oracle."""
+    g, Mo, M = pathqr_models(hip, golden_dir)
+    N, B = Mo.T, 150
+    r = np.random.RandomState(5)
+    x0 = co.cartpole_batch(B, T=N, seed_x=71, seed_u=72)[0]
+    us = r.uniform(-3, 3, (B, N, 1))
+    xs_ref, J_ref = co.rollout_cost(Mo, x0, us)
+    xs_bm, J = hip.rollout_cost_bm(M, B, hip.pack_bm(dev(x0)), hip.pack_bm(dev(us)))
+    assert eq(hip.unpack_bm(xs_bm, B, (N + 1, 5)).cpu().numpy(), xs_ref) and eq(J.cpu().numpy()[:B], J_ref)
+    us_bm = hip.pack_bm(dev(us))
+    d = hip.deriv_bm(M, B, xs_bm, us_bm)
+    for b in (0, 77, B - 1):
+        dr = co.derivatives(Mo, xs_ref[b], us[b])
+        assert eq(hip.unpack_bm(d["lx"], B, (N, 5)).cpu().numpy()[b], dr["lx"])
+        assert eq(hip.unpack_bm(d["lu"], B, (N, 1)).cpu().numpy()[b], dr["lu"])
+        assert eq(hip.unpack_bm(d["lxT"], B, (5,)).cpu().numpy()[b], dr["lxT"])
+        assert eq(hip.unpack_bm(d["lxx"], B, (N, 5, 5)).cpu().numpy()[b], dr["lxx"])
+    mu = np.full(B, 0.5)
+    bw_ref = co.backward(Mo, co.Opts(), xs_ref, us, mu)
+    bw = hip.backward_bm(M, hip.Opts(), B, xs_bm, us_bm, dev(mu))
+    k, K = hip.unpack_bm(bw["k"], B, (N, 1)).cpu().numpy(), hip.unpack_bm(bw["K"], B, (N, 1, 5)).cpu().numpy()
+    assert eq(k, bw_ref["k"]) and eq(K, bw_ref["K"])
+    alphas = co.line_search_alphas(6)
+    _, _, J_ref_a = co.forward(Mo, alphas, xs_ref, us, bw_ref["k"], bw_ref["K"])
+    J_a, _, _ = hip.forward_ls_bm(M, B, alphas, xs_bm, us_bm, bw["k"], bw["K"])
+    assert eq(J_a.cpu().numpy()[:, :B].T, J_ref_a)
+
+
+def test_pathqr_solve_bit_exact_and_matches_reference_run(hip, golden_dir):
+    g, Mo, M = pathqr_models(hip, golden_dir)
+    N = Mo.T
+    # the three recorded reference runs: identical decisions, costs within 1e-9 relative
+    for i in range(int(g["n_problems"])):
+        p = "p%d_" % i
+        out = hip.solve(M, hip.Opts(max_iter=int(g[p + "max_iter"])), dev(g[p + "x0"][None]), dev(g[p + "us_init"][None]),
+                        trace=True)
+        it = int(out["iters"][0])
+        assert it == len(g[p + "it_J"])
+        np.testing.assert_allclose(out["trace"]["J"][:it, 0].cpu().numpy(), g[p + "it_J"], rtol=1e-9)
+        assert np.array_equal(out["trace"]["accepted"][:it, 0].cpu().numpy().astype(bool), g[p + "it_accepted"])
+        np.testing.assert_allclose(out["us"][0].cpu().numpy(), g[p + "us"], rtol=0, atol=1e-8)
+    # a batch against the oracle, bit for bit
+    B = 200
+    x0, us0 = co.cartpole_batch(B, T=N, seed_x=81, seed_u=82)
+    ref = co.solve(Mo, co.Opts(max_iter=60), x0, us0, nthreads=8, trace=False)
+    out = hip.solve(M, hip.Opts(max_iter=60), dev(x0), dev(us0))
+    for key in ("xs", "us", "J", "k", "K", "mu", "delta"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+
+
 def test_plant_step_bit_exact(hip):
     r = np.random.RandomState(8)
     st = r.uniform(-3, 3, (1000, 4))

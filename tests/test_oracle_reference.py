@@ -49,6 +49,39 @@ def test_update_u_matches_reference_run(solve_vec, tag, math_mode):
         np.testing.assert_allclose(out["K"][0], g[p + "K"], rtol=1e-7, atol=1e-7)
 
 
+def pathqr_model(g, math_mode):
+    N = int(g["N"])
+    return co.Model(co.MODEL_CARTPOLE, 5, 1, N, co.COST_PATHQR, math_mode, True, dt=0.05, Q=g["Q"], R=g["R"],
+                    Q_terminal=g["Qt"], x_goal=g["x_path"], u_goal=g["u_path"], lower=[-5.0], upper=[5.0])
+
+
+@pytest.mark.parametrize("math_mode", [co.MATH_LIBM, co.MATH_DET])
+def test_pathqr_update_u_matches_reference_run(golden_dir, math_mode):
+    """The reference's PathQRCost (ilqr_cost.py:635-770: time-indexed goals, no 1/2 in the value,
+    a non-symmetric Q) driving its update_u."""
+    g = np.load(golden_dir + "/ref_pathqr_solve.npz")
+    M = pathqr_model(g, math_mode)
+    N = int(g["N"])
+    for i in range(int(g["n_problems"])):
+        p = "p%d_" % i
+        out = co.solve(M, co.Opts(max_iter=int(g[p + "max_iter"])), g[p + "x0"], g[p + "us_init"])
+        tr, it = out["trace"], int(out["iters"][0])
+        ref_J = g[p + "it_J"]
+        assert it == len(ref_J), i
+        np.testing.assert_allclose(tr["J"][0, :it], ref_J, rtol=RTOL_J)
+        assert np.array_equal(tr["accepted"][0, :it].astype(bool), g[p + "it_accepted"])
+        assert np.array_equal(_n_forward(tr["alpha_idx"][0, :it]), g[p + "it_n_forward"])
+        assert np.array_equal(tr["mu"][0, :it], g[p + "it_mu"])
+        assert bool(out["converged"][0]) == bool(g[p + "it_converged"][-1])
+        np.testing.assert_allclose(out["xs"][0], g[p + "xs"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(out["us"][0], g[p + "us"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(out["K"][0], g[p + "K"], rtol=1e-7, atol=1e-7)
+        # the cost functions themselves at one interior step and at the end
+        d = co.derivatives(M, g[p + "xs"], g[p + "us"])
+        np.testing.assert_allclose(d["lx"][3], g[p + "lx0"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(d["lu"][3], g[p + "lu0"], rtol=1e-12, atol=1e-12)
+
+
 def test_boxqp_matches_reference(golden_dir):
     g = np.load(golden_dir + "/ref_boxqp.npz")
     n = int(g["n_cases"])
