@@ -474,10 +474,11 @@ constexpr int LS_MAXA = 32;  // largest alpha schedule
 // (problem, alpha)); only the cost changes: a rejected iteration needs ~3 rollout
 // times instead of 30, which removes the straggler waves that otherwise set the
 // kernel's duration.
-// OCC = waves per SIMD the register budget is sized for: 1 (up to 512 registers, no
-// spills) while the batch gives every SIMD at most one wave, 2 beyond that.
-template <class Cost, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_solve(CartpoleP mp, QRCostP Cp, SolveOptsP O, BoundsP bd, int T,
+// Compiled for one wave per SIMD (up to 512 registers, no spills): a build for two
+// waves per SIMD spills ~400 bytes per lane and is slower at every batch size measured
+// (158 vs 114 ms at 65536 problems, 227 vs 214 ms at 131072).
+template <class Cost>
+__global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, SolveOptsP O, BoundsP bd, int T,
                                                 int64_t B, SolveBuffers W,
                                                 double* __restrict__ delta_io,
                                                 double* __restrict__ J_out, double* __restrict__ mu_out,
@@ -1359,25 +1360,16 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
     if (const char* e = std::getenv("ILQR_SOLVE_BLOCK"))
         blk = std::atoi(e) == 256 ? 256 : WAVE;
     dim3 grid((unsigned)((B + blk - 1) / blk));
-    int occ = B > 64 * 1024 ? 2 : 1; // more than one wave per SIMD to place?
-    if (const char* e = std::getenv("ILQR_SOLVE_OCC"))
-        occ = std::atoi(e) == 2 ? 2 : 1;
     int ev = cost_eval(C);
-#define ILQR_LAUNCH_SOLVE(COST, OCC)                                                                          \
-    hipLaunchKernelGGL((k_solve<COST, OCC>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, \
-                       iters, status, tr)
-    if (ev == EVAL_DIAG && occ == 1)
-        ILQR_LAUNCH_SOLVE(DiagQR, 1);
-    else if (ev == EVAL_DIAG)
-        ILQR_LAUNCH_SOLVE(DiagQR, 2);
-    else if (ev == EVAL_DENSE && occ == 1)
-        ILQR_LAUNCH_SOLVE(DenseQR, 1);
+#define ILQR_LAUNCH_SOLVE(COST)                                                                               \
+    hipLaunchKernelGGL((k_solve<COST>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, iters, \
+                       status, tr)
+    if (ev == EVAL_DIAG)
+        ILQR_LAUNCH_SOLVE(DiagQR);
     else if (ev == EVAL_DENSE)
-        ILQR_LAUNCH_SOLVE(DenseQR, 2);
-    else if (occ == 1)
-        ILQR_LAUNCH_SOLVE(PathQR, 1);
+        ILQR_LAUNCH_SOLVE(DenseQR);
     else
-        ILQR_LAUNCH_SOLVE(PathQR, 2);
+        ILQR_LAUNCH_SOLVE(PathQR);
 #undef ILQR_LAUNCH_SOLVE
     hipLaunchKernelGGL(k_unpack, tile_grid(B, (T + 1) * 5), dim3(256), 0, st, (const double*)W.xs[0],
                        (const double*)W.xs[1], (const int32_t*)W.sel_traj, xs, B, (T + 1) * 5, tiled);

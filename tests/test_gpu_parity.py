@@ -428,6 +428,24 @@ def test_boxqp1_on_captured_backward_pass_inputs(hip):
     assert eq(out["Hff"].cpu().numpy()[:, 0, 0], ref["Hff"][:, 0, 0])
 
 
+def test_workgroup_shapes_agree(hip, monkeypatch):
+    """Large batches run 4-wave workgroups, small ones 1-wave workgroups; forcing either on
+    the same ragged batch must give the same bits (each wave only talks to itself)."""
+    B, T = 700, 40
+    Mo = co.cartpole_model(T=T)
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=43, seed_u=44)
+    M = hip_model(hip, Mo)
+    outs = []
+    for blk in ("64", "256"):
+        monkeypatch.setenv("ILQR_SOLVE_BLOCK", blk)
+        outs.append(hip.solve(M, hip.Opts(max_iter=30), dev(x0), dev(us0)))
+    monkeypatch.delenv("ILQR_SOLVE_BLOCK")
+    for key in ("xs", "us", "J", "k", "K", "mu", "delta", "iters", "status"):
+        assert eq(outs[0][key].cpu().numpy(), outs[1][key].cpu().numpy()), key
+    ref = co.solve(Mo, co.Opts(max_iter=30), x0, us0, nthreads=8, trace=False)
+    assert eq(outs[1]["us"].cpu().numpy(), ref["us"]) and np.array_equal(outs[1]["iters"].cpu().numpy(), ref["iters"])
+
+
 def test_dense_and_diagonal_cost_evaluators_agree(hip, monkeypatch):
     """A diagonal Q takes the evaluator that skips the zero products; forcing the
     dense one must give the same bits, and a full Q must match the oracle."""
