@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
-MODEL_CARTPOLE, MODEL_LINEAR = 0, 1
+MODEL_CARTPOLE, MODEL_LINEAR, MODEL_SIGMOID = 0, 1, 2
 COST_QR, COST_PATHQR = 0, 1
 MATH_LIBM, MATH_DET = 0, 1
 
@@ -31,6 +31,7 @@ class _ModelC(C.Structure):
         ("dt", C.c_double), ("mc", C.c_double), ("mp", C.c_double), ("l", C.c_double), ("g", C.c_double),
         ("A", _dp), ("B", _dp), ("Q", _dp), ("R", _dp), ("Qt", _dp),
         ("x_goal", _dp), ("u_goal", _dp), ("lower", _dp), ("upper", _dp),
+        ("W", _dp), ("sig_c", C.c_double),
     ]
 
 
@@ -87,12 +88,15 @@ class Model:
 
     def __init__(self, model=MODEL_CARTPOLE, n=5, m=1, T=100, cost_kind=COST_QR, math_mode=MATH_DET,
                  control_limit=True, dt=0.05, mc=1.0, mp=0.1, l=1.0, g=9.8, A=None, B=None,
-                 Q=None, R=None, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None):
+                 Q=None, R=None, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
+                 W=None, sig_c=0.0):
         self.n, self.m, self.T = n, m, T
         self.model, self.cost_kind, self.math_mode = model, cost_kind, math_mode
         self.control_limit = bool(control_limit)
         self.A = None if A is None else _f64(A).reshape(n, n)
         self.B = None if B is None else _f64(B).reshape(n, m)
+        self.W = None if W is None else _f64(W).reshape(n, n)
+        self.sig_c = float(sig_c)
         self.Q = _f64(Q).reshape(n, n)
         self.R = _f64(R).reshape(m, m)
         self.Qt = self.Q if Q_terminal is None else _f64(Q_terminal).reshape(n, n)
@@ -110,11 +114,13 @@ class Model:
         c.cost_kind, c.math_mode, c.control_limit = cost_kind, math_mode, int(self.control_limit)
         c.dt, c.mc, c.mp, c.l, c.g = dt, mc, mp, l, g
         c.A, c.B = _p(self.A), _p(self.B)
+        c.W, c.sig_c = _p(self.W), self.sig_c
         c.Q, c.R, c.Qt = _p(self.Q), _p(self.R), _p(self.Qt)
         c.x_goal, c.u_goal = _p(self.x_goal), _p(self.u_goal)
         c.lower, c.upper = _p(self.lower), _p(self.upper)
         self.c = c
         self.params = dict(dt=dt, mc=mc, mp=mp, l=l, g=g)
+        self.dt = dt
 
     def with_math(self, math_mode):
         import copy
@@ -307,3 +313,23 @@ def cartpole_batch(B, T=100, seed_x=1, seed_u=2):
                    r.uniform(-1, 1, B)], axis=1)
     us = np.random.RandomState(seed_u).uniform(-1, 1, (B, T, 1))
     return augment_state(st), us
+
+
+def synthetic_model(n=32, m=8, T=200, seed=4, dt=0.05, sig_c=2.0, u_max=1.0, math_mode=MATH_DET):
+    """The large-state workload (no counterpart in the reference, which ships no model of this
+    size): x+ = x + dt (A x + B u + c phi(W x)), phi(z) = z / sqrt(1 + z^2), with a stable random
+    A, random B and W, QRCost towards the origin and box limits |u| <= u_max."""
+    r = np.random.RandomState(seed)
+    G = r.randn(n, n)
+    A = 0.8 * G / np.abs(np.linalg.eigvals(G)).max() - np.eye(n)
+    Bm = r.randn(n, m) / np.sqrt(m)
+    W = r.randn(n, n) / np.sqrt(n)
+    Q, R, Qt = np.eye(n), 0.1 * np.eye(m), 10.0 * np.eye(n)
+    return Model(MODEL_SIGMOID, n, m, T, COST_QR, math_mode, True, dt=dt, A=A, B=Bm, W=W, sig_c=sig_c, Q=Q, R=R,
+                 Q_terminal=Qt, lower=np.full(m, -u_max), upper=np.full(m, u_max))
+
+
+def synthetic_batch(B, n=32, m=8, T=200, seed_x=5, seed_u=6):
+    x0 = np.random.RandomState(seed_x).uniform(-1.0, 1.0, (B, n))
+    us = np.random.RandomState(seed_u).uniform(-0.5, 0.5, (B, T, m))
+    return x0, us

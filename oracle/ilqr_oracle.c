@@ -45,7 +45,7 @@
 #define NMAX 32
 #define MMAX 8
 
-enum { MODEL_CARTPOLE = 0, MODEL_LINEAR = 1 };
+enum { MODEL_CARTPOLE = 0, MODEL_LINEAR = 1, MODEL_SIGMOID = 2 };
 enum { COST_QR = 0, COST_PATHQR = 1 };
 enum { MATH_LIBM = 0, MATH_DET = 1 };
 
@@ -57,6 +57,11 @@ typedef struct {
     int control_limit;
     double dt, mc, mp, l, g;   /* cartpole (cartpole.py:8) */
     const double *A, *B;       /* linear model x+ = A x + B u : [n*n], [n*m] */
+    /* synthetic nonlinear model (no counterpart in the reference; it exists to exercise the
+     * large-state path): x+ = x + dt (A x + B u + c phi(W x)), phi(z) = z / sqrt(1 + z^2),
+     * applied element-wise.  W [n*n], c = sig_c, dt as above. */
+    const double *W;
+    double sig_c;
     const double *Q, *R, *Qt;  /* [n*n], [m*m], [n*n] */
     const double *x_goal;      /* QR: [n]; PathQR: [(T+1)*n] */
     const double *u_goal;      /* QR: [m]; PathQR: [T*m] */
@@ -197,6 +202,22 @@ static void model_f(const oracle_model *P, const double *x, const double *u, dou
         return;
     }
     int n = P->n, m = P->m;
+    if (P->model == MODEL_SIGMOID) {
+        for (int i = 0; i < n; ++i) {
+            double ax = P->A[i * n + 0] * x[0], z = P->W[i * n + 0] * x[0];
+            for (int j = 1; j < n; ++j) {
+                ax = fma(P->A[i * n + j], x[j], ax);
+                z = fma(P->W[i * n + j], x[j], z);
+            }
+            double bu = P->B[i * m + 0] * u[0];
+            for (int j = 1; j < m; ++j)
+                bu = fma(P->B[i * m + j], u[j], bu);
+            double s = 1.0 + z * z;
+            double phi = z / sqrt(s);
+            out[i] = x[i] + P->dt * ((ax + bu) + P->sig_c * phi);
+        }
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         double acc = P->A[i * n + 0] * x[0];
         for (int j = 1; j < n; ++j)
@@ -212,6 +233,22 @@ static void model_fx_fu(const oracle_model *P, const double *x, const double *u,
 {
     if (P->model == MODEL_CARTPOLE) {
         cartpole_fx_fu(P, x, u, fx, fu);
+        return;
+    }
+    if (P->model == MODEL_SIGMOID) {
+        /* f_x = I + dt (A + c diag(phi'(W x)) W), phi'(z) = 1 / ((1 + z^2) sqrt(1 + z^2)); f_u = dt B */
+        int n = P->n, m = P->m;
+        for (int i = 0; i < n; ++i) {
+            double z = P->W[i * n + 0] * x[0];
+            for (int j = 1; j < n; ++j)
+                z = fma(P->W[i * n + j], x[j], z);
+            double s = 1.0 + z * z;
+            double gi = P->sig_c * (1.0 / (s * sqrt(s)));
+            for (int j = 0; j < n; ++j)
+                fx[i * n + j] = (i == j ? 1.0 : 0.0) + P->dt * (P->A[i * n + j] + gi * P->W[i * n + j]);
+            for (int j = 0; j < m; ++j)
+                fu[i * m + j] = P->dt * P->B[i * m + j];
+        }
         return;
     }
     memcpy(fx, P->A, sizeof(double) * P->n * P->n);
@@ -979,6 +1016,8 @@ typedef struct {
     int model, n, m, T, cost_kind, math_mode, control_limit, pad_;
     double dt, mc, mp, l, g;
     const double *A, *B, *Q, *R, *Qt, *x_goal, *u_goal, *lower, *upper;
+    const double *W;
+    double sig_c;
 } oracle_model_c;
 
 static oracle_model to_model(const oracle_model_c *c)
@@ -989,6 +1028,7 @@ static oracle_model to_model(const oracle_model_c *c)
     P.dt = c->dt; P.mc = c->mc; P.mp = c->mp; P.l = c->l; P.g = c->g;
     P.A = c->A; P.B = c->B; P.Q = c->Q; P.R = c->R; P.Qt = c->Qt;
     P.x_goal = c->x_goal; P.u_goal = c->u_goal; P.lower = c->lower; P.upper = c->upper;
+    P.W = c->W; P.sig_c = c->sig_c;
     return P;
 }
 
