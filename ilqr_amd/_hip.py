@@ -32,6 +32,15 @@ class ModelC(C.Structure):
     ]
 
 
+class LargeModelC(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("pad_", C.c_int32),
+        ("dt", C.c_double), ("sig_c", C.c_double),
+        ("A", _vp), ("B", _vp), ("W", _vp), ("Q", _vp), ("R", _vp), ("Q_terminal", _vp),
+        ("x_goal", _vp), ("u_goal", _vp), ("lower", _vp), ("upper", _vp),
+    ]
+
+
 class OptsC(C.Structure):
     _fields_ = [
         ("max_iter", C.c_int32), ("n_alpha", C.c_int32), ("alphas", _dp),
@@ -58,6 +67,8 @@ EXPORTS = (
     "ilqr_rollout_cost_bm", "ilqr_deriv_bm", "ilqr_backward_bm", "ilqr_forward_ls_bm",
     "ilqr_boxqp_batched", "ilqr_solve_workspace_bytes", "ilqr_solve_batched",
     "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
+    "ilqr_large_rollout_cost", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
+    "ilqr_large_solve_batched",
 )
 
 _lib = None
@@ -80,6 +91,8 @@ def lib():
         L.ilqr_bm_ld.argtypes = [C.c_int64]
         L.ilqr_solve_workspace_bytes.restype = C.c_size_t
         L.ilqr_solve_workspace_bytes.argtypes = [C.POINTER(ModelC), C.c_int64]
+        L.ilqr_large_workspace_bytes.restype = C.c_size_t
+        L.ilqr_large_workspace_bytes.argtypes = [C.POINTER(LargeModelC), C.c_int64]
         _lib = L
     return _lib
 
@@ -338,3 +351,105 @@ def detmath(a, b):
     check(lib().ilqr_detmath(C.c_int64(n), _ptr(_req(a, torch.float64)), _ptr(_req(b, torch.float64)),
                              *[_ptr(o) for o in outs], _stream()))
     return outs
+
+
+# ---- large-state path (n = 32, m = 8, one problem per wavefront) -----------------------------
+
+class LargeModel:
+    """Synthetic model x+ = x + dt (A x + B u + c phi(W x)) with a QRCost and box limits; every
+    array is uploaded once and kept alive by this object."""
+
+    def __init__(self, T, A, B, W, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
+                 dt=0.05, sig_c=2.0, device=None):
+        import torch
+        n, m = 32, 8
+        self.n, self.m, self.T = n, m, int(T)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+
+        def up(a, shape):
+            return torch.tensor(_host(a, shape), device=dev)
+        self.t = dict(
+            A=up(A, (n, n)), B=up(B, (n, m)), W=up(W, (n, n)), Q=up(Q, (n, n)), R=up(R, (m, m)),
+            Q_terminal=up(Q if Q_terminal is None else Q_terminal, (n, n)),
+            x_goal=up(np.zeros(n) if x_goal is None else x_goal, (n,)),
+            u_goal=up(np.zeros(m) if u_goal is None else u_goal, (m,)),
+            lower=up(lower, (m,)), upper=up(upper, (m,)))
+        c = LargeModelC()
+        c.n, c.m, c.T, c.dt, c.sig_c = n, m, int(T), dt, sig_c
+        for name, t in self.t.items():
+            setattr(c, name, t.data_ptr())
+        self.c = c
+
+
+def large_rollout_cost(M, x0, us):
+    import torch
+    B = x0.shape[0]
+    xs = torch.empty((B, M.T + 1, M.n), dtype=torch.float64, device=x0.device)
+    J = torch.empty(B, dtype=torch.float64, device=x0.device)
+    check(lib().ilqr_large_rollout_cost(C.byref(M.c), C.c_int64(B), _ptr(_req(x0, torch.float64)),
+                                        _ptr(_req(us, torch.float64)), _ptr(xs), _ptr(J), _stream()))
+    return xs, J
+
+
+def large_backward(M, O, xs, us, mu, want_masks=True):
+    import torch
+    B, dev = xs.shape[0], xs.device
+    k = torch.empty((B, M.T, M.m), dtype=torch.float64, device=dev)
+    K = torch.empty((B, M.T, M.m, M.n), dtype=torch.float64, device=dev)
+    dJ = torch.empty((2, B), dtype=torch.float64, device=dev)
+    info = torch.empty((5, B), dtype=torch.int32, device=dev)
+    qres = torch.empty((B, M.T), dtype=torch.int32, device=dev) if want_masks else None
+    free = torch.empty((B, M.T, M.m), dtype=torch.int32, device=dev) if want_masks else None
+    check(lib().ilqr_large_backward(C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
+                                    _ptr(_req(us, torch.float64)), _ptr(_req(mu, torch.float64)), _ptr(k), _ptr(K),
+                                    _ptr(dJ), _ptr(info), _ptr(qres), _ptr(free), _stream()))
+    return dict(k=k, K=K, dJ=dJ, info=info, qp_result=qres, free=free)
+
+
+def large_forward_ls(M, alphas, xs, us, k, K, store_idx=-1):
+    import torch
+    B, dev = xs.shape[0], xs.device
+    al = _host(alphas, (-1,))
+    J = torch.empty((B, len(al)), dtype=torch.float64, device=dev)
+    xs_new = torch.empty_like(xs) if store_idx >= 0 else None
+    us_new = torch.empty_like(us) if store_idx >= 0 else None
+    check(lib().ilqr_large_forward_ls(C.byref(M.c), C.c_int64(B), C.c_int32(len(al)), al.ctypes.data_as(_dp),
+                                      C.c_int32(store_idx), _ptr(_req(xs, torch.float64)),
+                                      _ptr(_req(us, torch.float64)), _ptr(_req(k, torch.float64)),
+                                      _ptr(_req(K, torch.float64)), _ptr(J), _ptr(xs_new), _ptr(us_new), _stream()))
+    return J, xs_new, us_new
+
+
+def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, mu=None):
+    import torch
+    B, dev = x0.shape[0], x0.device
+    T, n, m = M.T, M.n, M.m
+    delta = torch.full((B,), 2.0, dtype=torch.float64, device=dev) if delta is None else delta
+    k = torch.zeros((B, T, m), dtype=torch.float64, device=dev) if k is None else k
+    K = torch.zeros((B, T, m, n), dtype=torch.float64, device=dev) if K is None else K
+    res = dict(xs=torch.empty((B, T + 1, n), dtype=torch.float64, device=dev),
+               us=torch.empty((B, T, m), dtype=torch.float64, device=dev),
+               J=torch.empty(B, dtype=torch.float64, device=dev),
+               mu=torch.ones(B, dtype=torch.float64, device=dev) if mu is None else mu,
+               iters=torch.empty(B, dtype=torch.int32, device=dev),
+               status=torch.empty(B, dtype=torch.int32, device=dev))
+    need = int(lib().ilqr_large_workspace_bytes(C.byref(M.c), C.c_int64(B)))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    tr_c, tr = None, None
+    if trace:
+        tr, tr_c = {}, TraceC()
+        for name, dt in TRACE_FIELDS:
+            if dt == "f8":
+                t = torch.full((O.max_iter, B), float("nan"), dtype=torch.float64, device=dev)
+            else:
+                t = torch.full((O.max_iter, B), -1, dtype=torch.int32, device=dev)
+            tr[name] = t
+            setattr(tr_c, name, t.data_ptr())
+    check(lib().ilqr_large_solve_batched(
+        C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(x0, torch.float64)), _ptr(_req(us_init, torch.float64)),
+        _ptr(_req(delta, torch.float64)), _ptr(_req(k, torch.float64)), _ptr(_req(K, torch.float64)),
+        _ptr(res["xs"]), _ptr(res["us"]), _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),
+        C.byref(tr_c) if tr_c is not None else None, _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
+    res.update(delta=delta, k=k, K=K, trace=tr, workspace=workspace)
+    return res

@@ -193,6 +193,51 @@ int ilqr_debug_wave_log(void* device_buffer);
 int ilqr_detmath(int64_t n, const double* a, const double* b, double* sin_a, double* cos_a,
                  double* atan2_ab, double* sqrt_abs_a, double* a_over_b, void* stream);
 
+/* ---- large-state path: n = 32 states, m = 8 controls, one problem per wavefront ----
+ *
+ * The reference ships no model of this size; the path exists for its generic machinery
+ * (the same update_u / _backward_pass / boxQP / _forward_pass, ilqr_core.py:85-399 and
+ * ilqr_boxQP.py:9-186, with dense 32 x 32 and 8 x 8 matrices) and runs the synthetic model
+ *     x+ = x + dt (A x + B u + c phi(W x)),   phi(z) = z / sqrt(1 + z^2) element-wise,
+ * with a QRCost (ilqr/ilqr_cost.py:490-632) and box limits on u.  Arrays are in the
+ * reference's own layout ([B,T+1,n], [B,T,m], [B,T,m,n]); no batch-minor conversion.
+ * Every pointer of this struct is a DEVICE pointer (the matrices are read by the kernels). */
+typedef struct ilqr_large_model {
+    int32_t n, m, T;  /* n must be 32, m must be 8 */
+    int32_t pad_;
+    double dt, sig_c; /* step and the gain c of the non-linearity */
+    const double *A, *B, *W;          /* [n*n], [n*m], [n*n] row-major */
+    const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] */
+    const double *x_goal, *u_goal;    /* [n], [m] */
+    const double *lower, *upper;      /* [m] */
+} ilqr_large_model;
+
+/* iLQR._dynamics_rollout + _trajectory_cost (ilqr_core.py:69-83, :230-239):
+ * x0 [B,n], us [B,T,m] -> xs [B,T+1,n], J [B]. */
+int ilqr_large_rollout_cost(const ilqr_large_model* model, int64_t B, const double* x0, const double* us,
+                            double* xs, double* J, void* stream);
+
+/* iLQR._backward_pass (ilqr_core.py:109-228) with boxQP: xs, us, mu [B] -> k [B,T,m],
+ * K [B,T,m,n], dJ [2,B], info [5,B] (as ilqr_backward_bm with ld = B); optional
+ * qp_result [B,T] and free_mask [B,T,m]. */
+int ilqr_large_backward(const ilqr_large_model* model, const ilqr_opts* opts, int64_t B, const double* xs,
+                        const double* us, const double* mu, double* k, double* K, double* dJ, int32_t* info,
+                        int32_t* qp_result, int32_t* free_mask, void* stream);
+
+/* iLQR._forward_pass + _trajectory_cost (ilqr_core.py:85-107) for n_alpha step sizes (HOST array),
+ * 16 at a time as the columns of one matrix: J_new [B, n_alpha]; the trajectory of
+ * alphas[store_idx] goes to xs_new [B,T+1,n], us_new [B,T,m] (store_idx < 0: none). */
+int ilqr_large_forward_ls(const ilqr_large_model* model, int64_t B, int32_t n_alpha, const double* alphas,
+                          int32_t store_idx, const double* xs, const double* us, const double* k, const double* K,
+                          double* J_new, double* xs_new, double* us_new, void* stream);
+
+/* iLQR.update_u (ilqr_core.py:241-399), arguments as ilqr_solve_batched. */
+size_t ilqr_large_workspace_bytes(const ilqr_large_model* model, int64_t B);
+int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                             const double* us_init, double* delta, double* k, double* K, double* xs, double* us,
+                             double* J, double* mu, int32_t* iters, int32_t* status, const ilqr_trace* trace,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""GPU parity tests of the large-state path (n = 32, m = 8, one problem per wavefront, fp64 MFMA)
+against the CPU oracle.  The reference ships no model of this size (parity unpinned against it);
+the oracle's generic solver code is the one pinned by the cart-pole reference runs, applied to
+the synthetic model x+ = x + dt (A x + B u + c phi(W x)).  Bar: == on every value (the MFMA
+accumulates exactly the oracle's left-to-right fma chains) and on every integer."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as co  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ilqr_amd import _hip
+    _hip.lib()
+    return _hip
+
+
+def dev(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda:0")
+
+
+def eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def models(hip, T):
+    Mo = co.synthetic_model(T=T)
+    M = hip.LargeModel(T, Mo.A, Mo.B, Mo.W, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=Mo.dt,
+                       sig_c=Mo.sig_c)
+    return Mo, M
+
+
+def test_large_rollout_cost_bit_exact(hip):
+    T, B = 50, 37
+    Mo, M = models(hip, T)
+    x0, us = co.synthetic_batch(B, T=T)
+    us *= 3.0
+    xs_ref, J_ref = co.rollout_cost(Mo, x0, us)
+    xs, J = hip.large_rollout_cost(M, dev(x0), dev(us))
+    assert eq(xs.cpu().numpy(), xs_ref) and eq(J.cpu().numpy(), J_ref)
+
+
+@pytest.mark.parametrize("scale_u,mu", [(1.0, 1.0), (4.0, 0.0), (2.0, 50.0)])
+def test_large_backward_bit_exact(hip, scale_u, mu):
+    T, B = 40, 21
+    Mo, M = models(hip, T)
+    x0, us = co.synthetic_batch(B, T=T, seed_x=7, seed_u=8)
+    us *= scale_u
+    xs, _ = co.rollout_cost(Mo, x0, us)
+    mus = np.full(B, mu)
+    ref = co.backward(Mo, co.Opts(), xs, us, mus)
+    out = hip.large_backward(M, hip.Opts(), dev(xs), dev(us), dev(mus))
+    assert eq(out["k"].cpu().numpy(), ref["k"]) and eq(out["K"].cpu().numpy(), ref["K"])
+    dJ, info = out["dJ"].cpu().numpy(), out["info"].cpu().numpy()
+    assert eq(dJ[0], ref["dJ1"]) and eq(dJ[1], ref["dJ2"])
+    assert np.array_equal(info[0], ref["stopped_at"]) and np.array_equal(info[1], ref["qp_iter"])
+    assert np.array_equal(info[2], ref["qp_backtrack"]) and np.array_equal(info[3], ref["n_clamped"])
+    assert np.array_equal(out["qp_result"].cpu().numpy(), ref["qp_result"])
+    assert np.array_equal(out["free"].cpu().numpy(), ref["free"])
+    if scale_u >= 2.0:
+        assert (ref["n_clamped"] > 0).any()  # the box limits really bind
+
+
+def test_large_forward_line_search_bit_exact(hip):
+    T, B = 40, 19
+    Mo, M = models(hip, T)
+    x0, us = co.synthetic_batch(B, T=T, seed_x=9, seed_u=10)
+    xs, _ = co.rollout_cost(Mo, x0, us)
+    bw = co.backward(Mo, co.Opts(), xs, us, 1.0)
+    alphas = co.line_search_alphas(30)
+    xs_n, us_n, J_n = co.forward(Mo, alphas, xs, us, bw["k"], bw["K"])
+    for store in (0, 5, 21):
+        J, xs_new, us_new = hip.large_forward_ls(M, alphas, dev(xs), dev(us), dev(bw["k"]), dev(bw["K"]), store_idx=store)
+        assert eq(J.cpu().numpy(), J_n)
+        assert eq(xs_new.cpu().numpy(), xs_n[:, store]) and eq(us_new.cpu().numpy(), us_n[:, store])
+
+
+def test_large_solve_bit_exact(hip):
+    T, B = 60, 24
+    Mo, M = models(hip, T)
+    x0, us0 = co.synthetic_batch(B, T=T, seed_x=11, seed_u=12)
+    ref = co.solve(Mo, co.Opts(max_iter=25), x0, us0, nthreads=8)
+    out = hip.large_solve(M, hip.Opts(max_iter=25), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+    tr = {key: out["trace"][key].cpu().numpy().T for key in out["trace"]}
+    for b in range(B):
+        it = int(ref["iters"][b])
+        for key in ("J", "accepted", "alpha_idx", "mu", "delta", "qp_iter", "qp_backtrack", "n_clamped", "stopped_at"):
+            assert eq(tr[key][b, :it], ref["trace"][key][b, :it]), (b, key)
+    assert (ref["trace"]["n_clamped"] > 0).any() and (ref["status"] == 1).any()
