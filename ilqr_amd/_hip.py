@@ -68,7 +68,7 @@ EXPORTS = (
     "ilqr_boxqp_batched", "ilqr_solve_workspace_bytes", "ilqr_solve_batched",
     "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
     "ilqr_large_rollout_cost", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
-    "ilqr_large_solve_batched",
+    "ilqr_large_solve_batched", "ilqr_large_debug_profile",
 )
 
 _lib = None

@@ -133,8 +133,10 @@ struct LargeP { // kernel arguments: the model, all device pointers
 
 struct LQPOpts {
     int max_iter;
+    int n_exhaust; // number of step reductions after which step < min_step (host-simulated)
     double min_grad, min_rel, step_dec, min_step, armijo;
 };
+
 
 struct LSolveOpts {
     int max_iter, n_alpha, mu_from_array;
@@ -143,101 +145,123 @@ struct LSolveOpts {
     LQPOpts qp;
 };
 
-// ------------------------------------------------------------------ boxQP in LDS
-//
-// boxQP (ilqr_boxQP.py:9-186) for m = 8.  The state lives in LDS; every lane of the wave
-// executes the same scalar program on it (uniform control flow, broadcast reads, identical
-// stores), which keeps the 8 x 8 factorisations and the free-subspace bookkeeping a
-// transliteration of the reference.
-struct QPMem {
-    double H[LM * LM], g[LM], lo[LM], hi[LM], x[LM];
-    double Hff[LM * LM], Lfull[LM * LM], sub[LM * LM];
-    double grad[LM], search[LM], xc[LM], rhs[LM];
-    int clamped[LM], freev[LM], oldclamped[LM], fidx[LM], cidx[LM];
-};
+constexpr int LQ_TAB = 512; // Armijo steps tabulated per workgroup
 
 __device__ __forceinline__ double lclamp(double lo, double hi, double v)
 {
+    // np.maximum(lower, np.minimum(upper, x)) with NaN propagation (ilqr_boxQP.py:37)
     double t = (v != v) ? v : (hi < v ? hi : v);
     return (t != t) ? t : (lo > t ? lo : t);
 }
 
-__device__ double lq_quad(int m, const double* v, const double* M)
+// LDS traffic of one wave needs no workgroup barrier: the wave's LDS instructions execute in
+// order; this only keeps the compiler from moving accesses across the hand-over point.
+__device__ __forceinline__ void wave_sync()
 {
-    double tot = 0.0;
-    for (int j = 0; j < m; ++j) {
-        double acc = v[0] * M[j];
-        for (int i = 1; i < m; ++i)
-            acc = fma(v[i], M[i * m + j], acc);
-        tot = (j == 0) ? acc * v[0] : fma(acc, v[j], tot);
-    }
-    return tot;
-}
-__device__ double lq_value(int m, const double* H, const double* g, const double* x)
-{
-    double xg = x[0] * g[0];
-    for (int i = 1; i < m; ++i)
-        xg = fma(x[i], g[i], xg);
-    return xg + 0.5 * lq_quad(m, x, H);
-}
-__device__ int lq_chol(int d, const double* A, int lda, double* L, int ldl)
-{
-    for (int j = 0; j < d; ++j) {
-        double s = A[j * lda + j];
-        for (int k = 0; k < j; ++k)
-            s = fma(-L[j * ldl + k], L[j * ldl + k], s);
-        if (!(s > 0.0))
-            return 1;
-        double d_jj = sqrt(s);
-        double r_jj = 1.0 / d_jj;
-        L[j * ldl + j] = d_jj;
-        for (int i = j + 1; i < d; ++i) {
-            double t = A[i * lda + j];
-            for (int k = 0; k < j; ++k)
-                t = fma(-L[i * ldl + k], L[j * ldl + k], t);
-            L[i * ldl + j] = t * r_jj;
-        }
-    }
-    return 0;
-}
-__device__ void lq_solve(int d, const double* L, int ldl, double* b)
-{
-    for (int i = 0; i < d; ++i) {
-        double s = b[i];
-        for (int j = 0; j < i; ++j)
-            s = fma(-L[i * ldl + j], b[j], s);
-        b[i] = s * (1.0 / L[i * ldl + i]);
-    }
-    for (int i = d - 1; i >= 0; --i) {
-        double s = b[i];
-        for (int j = i + 1; j < d; ++j)
-            s = fma(-L[j * ldl + i], b[j], s);
-        b[i] = s * (1.0 / L[i * ldl + i]);
-    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-struct LQPOut {
-    int result, hd, nf, n_iter, n_factor, n_bt;
+// ------------------------------------------------------------------ boxQP in registers
+//
+// boxQP (ilqr_boxQP.py:9-186) for m = 8: every lane of the wave runs the same scalar program
+// (uniform control flow), with the 8-vectors and the 8 x 8 factor in registers and every loop
+// unrolled over the full index range; H is read from LDS (broadcast reads).  The reference compacts the free
+// variables before factorising and solving (ilqr_boxQP.py:114-132); here clamped rows and
+// columns of the factor are kept as exact zeros instead: fma(-0, 0, s) == s and b[j] == 0
+// for a clamped j, so every chain over the free indices has the same terms in the same
+// order and gives the same bits as the compacted computation.
+struct QPR {
+    double x[LM];
+    const double *g, *lo, *hi; // LDS
+    double (*Lf)[LM];          // LDS: masked lower factor of H_ff (all ones until the first factorisation, :36);
+                               // every lane stores the same values and reads back its own stores
+    bool fr[LM];       // free mask of the last classification
+    int result, n_iter, n_factor, n_bt, nf;
     bool linalg;
 };
 
-// H, g, lo, hi and the warm start (in Q.x) are in place.  Returns through Q.x, Q.Hff, Q.freev, Q.fidx.
-__device__ void lq_boxqp(const LQPOpts& O, QPMem& Q, LQPOut& out)
+// Lower Cholesky factor of H restricted to the free set; returns true if a free pivot is not > 0.
+__device__ __forceinline__ bool lr_chol(const double* H, const bool (&fr)[LM], double (*Lf)[LM])
 {
-    const int m = LM;
-    for (int i = 0; i < m * m; ++i)
-        Q.Hff[i] = 1.0;
-    bool h_finite = true;
-    for (int i = 0; i < m * m; ++i)
-        h_finite = h_finite && (fabs(Q.H[i]) < __builtin_inf());
-    for (int i = 0; i < m; ++i) {
-        Q.clamped[i] = 0;
-        Q.freev[i] = 0;
-        Q.x[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i]);
+    bool fail = false;
+#pragma unroll
+    for (int j = 0; j < LM; ++j) {
+        double s = H[j * LM + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+            s = fma(-Lf[j][k], Lf[j][k], s);
+        fail = fail || (fr[j] && !(s > 0.0));
+        double d = sqrt(s);
+        double r = 1.0 / d;
+        Lf[j][j] = fr[j] ? d : 1.0;
+#pragma unroll
+        for (int i = j + 1; i < LM; ++i) {
+            double t = H[i * LM + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k)
+                t = fma(-Lf[i][k], Lf[j][k], t);
+            Lf[i][j] = (fr[j] && fr[i]) ? t * r : 0.0;
+        }
     }
-    double value = lq_value(m, Q.H, Q.g, Q.x), oldvalue = 0.0;
-    int result = -1, hd = m, n_iter = 0, n_factor = 0, n_bt = 0, nf = 0;
-    bool h_pd = h_finite && lq_chol(m, Q.H, m, Q.Lfull, m) == 0;
+    return fail;
+}
+
+// cho_solve on the free set, b = 0 on clamped entries on exit
+__device__ __forceinline__ void lr_solve(const double (*Lf)[LM], const bool (&fr)[LM], double (&b)[LM])
+{
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+            s = fma(-Lf[i][j], b[j], s);
+        b[i] = fr[i] ? s * (1.0 / Lf[i][i]) : 0.0;
+    }
+#pragma unroll
+    for (int i = LM - 1; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = i + 1; j < LM; ++j)
+            s = fma(-Lf[j][i], b[j], s);
+        b[i] = fr[i] ? s * (1.0 / Lf[i][i]) : 0.0;
+    }
+}
+
+__device__ __forceinline__ double lr_value(const double* H, const double* g, const double (&x)[LM])
+{
+    double xg = x[0] * g[0];
+#pragma unroll
+    for (int i = 1; i < LM; ++i)
+        xg = fma(x[i], g[i], xg);
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < LM; ++j) {
+        double acc = x[0] * H[j];
+#pragma unroll
+        for (int i = 1; i < LM; ++i)
+            acc = fma(x[i], H[i * LM + j], acc);
+        tot = (j == 0) ? acc * x[0] : fma(acc, x[j], tot);
+    }
+    return xg + 0.5 * tot;
+}
+
+// H [64] (LDS, finite and positive definite: the caller has checked), steps: the wave's step table.
+// Q.x holds the warm start on entry.
+__device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps, QPR& Q)
+{
+    bool cl[LM];
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        cl[i] = false;
+        Q.fr[i] = false;
+        Q.x[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i]);
+#pragma unroll
+        for (int j = 0; j < LM; ++j)
+            Q.Lf[i][j] = 1.0;
+    }
+    double value = lr_value(H, Q.g, Q.x), oldvalue = 0.0;
+    int result = -1, n_iter = 0, n_factor = 0, n_bt = 0;
     bool linalg = false;
     for (int iter = 0; iter < O.max_iter; ++iter) {
         if (result != -1)
@@ -247,130 +271,193 @@ __device__ void lq_boxqp(const LQPOpts& O, QPMem& Q, LQPOut& out)
             break;
         }
         oldvalue = value;
-        for (int i = 0; i < m; ++i) {
-            double acc = Q.H[i * m] * Q.x[0];
-            for (int j = 1; j < m; ++j)
-                acc = fma(Q.H[i * m + j], Q.x[j], acc);
-            Q.grad[i] = Q.g[i] + acc;
-        }
+        double grad[LM];
+        bool changed = false;
         int nclamped = 0;
-        for (int i = 0; i < m; ++i) {
-            Q.oldclamped[i] = Q.clamped[i];
-            int cl = ((Q.x[i] == Q.lo[i]) && (Q.grad[i] > 0.0)) || ((Q.x[i] == Q.hi[i]) && (Q.grad[i] < 0.0));
-            Q.clamped[i] = cl;
-            Q.freev[i] = !cl;
-            nclamped += cl;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            double acc = H[i * LM] * Q.x[0];
+#pragma unroll
+            for (int j = 1; j < LM; ++j)
+                acc = fma(H[i * LM + j], Q.x[j], acc);
+            grad[i] = Q.g[i] + acc;
+            bool c = ((Q.x[i] == Q.lo[i]) && (grad[i] > 0.0)) || ((Q.x[i] == Q.hi[i]) && (grad[i] < 0.0));
+            changed = changed || (c != cl[i]);
+            cl[i] = c;
+            Q.fr[i] = !c;
+            nclamped += c ? 1 : 0;
         }
-        if (nclamped == m) {
+        if (nclamped == LM) {
             result = 6;
             break;
         }
-        if (!h_finite) {
-            linalg = true;
-            break;
-        }
-        if (!h_pd) {
-            result = -1;
-            break;
-        }
-        bool factorize = iter == 1;
-        for (int i = 0; i < m; ++i)
-            factorize = factorize || (Q.oldclamped[i] != Q.clamped[i]);
-        int nc = 0;
-        nf = 0;
-        for (int i = 0; i < m; ++i) {
-            if (Q.freev[i])
-                Q.fidx[nf++] = i;
-            else
-                Q.cidx[nc++] = i;
-        }
-        if (factorize) {
-            for (int a = 0; a < nf; ++a)
-                for (int b = 0; b < nf; ++b)
-                    Q.sub[a * m + b] = Q.H[Q.fidx[a] * m + Q.fidx[b]];
-            if (lq_chol(nf, Q.sub, m, Q.Hff, m) != 0) {
-                linalg = true;
+        if (iter == 1 || changed) {
+            if (lr_chol(H, Q.fr, Q.Lf)) {
+                linalg = true; // sla.cholesky raises LinAlgError
                 break;
             }
-            hd = nf;
             ++n_factor;
         }
-        double ss = 0.0;
-        for (int a = 0; a < nf; ++a) {
-            double ga = Q.grad[Q.fidx[a]];
-            ss = (a == 0) ? ga * ga : fma(ga, ga, ss);
+        // sla.norm(grad[free]); dnrm2 of a single element is its magnitude
+        double ss = 0.0, g1 = 0.0;
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
+            double sq = first ? grad[i] * grad[i] : fma(grad[i], grad[i], ss);
+            g1 = (Q.fr[i] && first) ? grad[i] : g1;
+            ss = Q.fr[i] ? sq : ss;
+            first = first && !Q.fr[i];
         }
-        double gnorm = nf == 1 ? fabs(Q.grad[Q.fidx[0]]) : sqrt(ss);
+        double gnorm = (LM - nclamped) == 1 ? fabs(g1) : sqrt(ss);
         if (gnorm < O.min_grad) {
             result = 5;
             break;
         }
         ++n_iter;
-        for (int a = 0; a < nf; ++a) {
+        // grad_clamped = g[free] + H_fc x[clamped]; search[free] = -cho_solve(H_ff, .) - x[free]
+        double rhs[LM], search[LM];
+#pragma unroll
+        for (int i = 0; i < LM; ++i) {
             double acc = 0.0;
-            for (int b = 0; b < nc; ++b) {
-                double h = Q.H[Q.fidx[a] * m + Q.cidx[b]], xv = Q.x[Q.cidx[b]];
-                acc = (b == 0) ? h * xv : fma(h, xv, acc);
+            bool f1 = true;
+#pragma unroll
+            for (int j = 0; j < LM; ++j) {
+                double t = f1 ? H[i * LM + j] * Q.x[j] : fma(H[i * LM + j], Q.x[j], acc);
+                acc = cl[j] ? t : acc;
+                f1 = f1 && !cl[j];
             }
-            Q.rhs[a] = Q.g[Q.fidx[a]] + acc;
+            rhs[i] = Q.fr[i] ? Q.g[i] + acc : 0.0;
         }
-        lq_solve(nf, Q.Hff, m, Q.rhs);
-        for (int i = 0; i < m; ++i)
-            Q.search[i] = 0.0;
-        for (int a = 0; a < nf; ++a)
-            Q.search[Q.fidx[a]] = Q.rhs[a] * -1 - Q.x[Q.fidx[a]];
+        lr_solve(Q.Lf, Q.fr, rhs);
+#pragma unroll
+        for (int i = 0; i < LM; ++i)
+            search[i] = Q.fr[i] ? rhs[i] * -1 - Q.x[i] : 0.0;
 
-        double step = 1.0;
-        for (int i = 0; i < m; ++i)
-            Q.xc[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i] + step * Q.search[i]);
-        double sdotg = (Q.xc[0] - Q.x[0]) * Q.grad[0];
-        for (int i = 1; i < m; ++i)
-            sdotg = sdotg + (Q.xc[i] - Q.x[i]) * Q.grad[i];
-        double vc = lq_value(m, Q.H, Q.g, Q.xc);
-        while ((vc - oldvalue) / (sdotg + 1e-10) < O.armijo) {
-            step = step * O.step_dec;
-            ++n_bt;
-            for (int i = 0; i < m; ++i)
-                Q.xc[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i] + step * Q.search[i]);
-            vc = lq_value(m, Q.H, Q.g, Q.xc);
-            sdotg = (Q.xc[0] - Q.x[0]) * Q.grad[0];
-            for (int i = 1; i < m; ++i)
-                sdotg = sdotg + (Q.xc[i] - Q.x[i]) * Q.grad[i];
-            if (step < O.min_step) {
-                result = 2;
+        // Armijo line search (:140-159).  The candidates of the reference's backtracking loop do
+        // not depend on each other, so the wave evaluates 64 consecutive trips at once (lane =
+        // trip, each lane runs the reference's scalar arithmetic for its own step) and takes the
+        // first trip at which the loop would have ended: the test fails, or the step has dropped
+        // below min_step (result 2).
+        const int ln = threadIdx.x & 63;
+        double step = 1.0; // only used by the serial fallback
+        for (int tb = 0;; tb += 64) {
+            int t = tb + ln;
+            bool tabulated = O.n_exhaust < LQ_TAB;
+            bool in_range = tabulated ? t <= O.n_exhaust : ln == 0;
+            double st = tabulated ? steps[in_range ? t : 0] : step;
+            double xc[LM];
+#pragma unroll
+            for (int i = 0; i < LM; ++i)
+                xc[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i] + st * search[i]);
+            double sdotg = (xc[0] - Q.x[0]) * grad[0];
+#pragma unroll
+            for (int i = 1; i < LM; ++i)
+                sdotg = sdotg + (xc[i] - Q.x[i]) * grad[i];
+            double vc = lr_value(H, Q.g, xc);
+            bool cont = (vc - oldvalue) / (sdotg + 1e-10) < O.armijo;
+            if (!tabulated) {
+                // one trip per pass on lane 0 (step tables longer than LQ_TAB are not kept)
+                int trip = tb / 64;
+                bool small = trip > 0 && st < O.min_step;
+                unsigned long long stopm = __ballot(ln == 0 && (!cont || small));
+                if (stopm != 0ull) {
+                    n_bt += trip;
+                    if (small)
+                        result = 2;
+#pragma unroll
+                    for (int i = 0; i < LM; ++i)
+                        Q.x[i] = __shfl(xc[i], 0);
+                    value = __shfl(vc, 0);
+                    break;
+                }
+                step = step * O.step_dec;
+                continue;
+            }
+            bool stop = in_range && (!cont || t == O.n_exhaust);
+            unsigned long long mask = __ballot(stop);
+            if (mask != 0ull) {
+                int w = __ffsll((long long)mask) - 1;
+                int tstar = tb + w;
+                n_bt += tstar;
+                if (tstar == O.n_exhaust)
+                    result = 2;
+#pragma unroll
+                for (int i = 0; i < LM; ++i)
+                    Q.x[i] = __shfl(xc[i], w);
+                value = __shfl(vc, w);
                 break;
             }
         }
-        for (int i = 0; i < m; ++i)
-            Q.x[i] = Q.xc[i];
-        value = vc;
     }
-    // the free set the caller uses is the one of the last classification
-    nf = 0;
-    for (int i = 0; i < m; ++i)
-        if (Q.freev[i])
-            Q.fidx[nf++] = i;
-    out.result = result;
-    out.hd = hd;
-    out.nf = nf;
-    out.n_iter = n_iter;
-    out.n_factor = n_factor;
-    out.n_bt = n_bt;
-    out.linalg = linalg;
+    int nf = 0;
+#pragma unroll
+    for (int i = 0; i < LM; ++i)
+        nf += Q.fr[i] ? 1 : 0;
+    Q.result = result;
+    Q.n_iter = n_iter;
+    Q.n_factor = n_factor;
+    Q.n_bt = n_bt;
+    Q.nf = nf;
+    Q.linalg = linalg;
 }
 
 // ------------------------------------------------------------------ per-wave LDS
 
-struct WaveMem {
-    QPMem qp;
-    double Quu[LM * LM], Qu[LM], kq[LM];
+struct WaveMem { // per problem (= per wave)
+    double H[LM * LM], g[LM], lo[LM], hi[LM], x[LM]; // Q_uu, Q_u, bounds, boxQP solution
+    double Lf[LM][LM];                               // boxQP factor
+    double vx[LN];                                   // parked V_x
+    double P1[LN][LN + 1];                           // parking space for a 32 x 32 tile set
     double Qux[LM][LN + 1];
     double K[LM][LN + 1];
     double Vn[LN][LN + 1];
     double J[LA];
 };
 
+struct BlockMem { // per workgroup: the model, shared by its four problems
+    double A[LN][LN + 1], W[LN][LN + 1], QQ[LN][LN + 1]; // QQ = Q + Q^T
+    double fu[LN][LM + 1];                               // dt B
+    double RR[LM][LM];                                   // R + R^T
+    double xg[LN], ug[LM], lower[LM], upper[LM];
+    double steps[LQ_TAB]; // 1, dec, dec*dec, ... with the Armijo loop's own rounded multiplications
+    WaveMem wv[4];
+};
+
+__device__ void block_init(BlockMem& M, const LargeP& P, double step_dec)
+{
+    for (int i = threadIdx.x; i < LN * LN; i += blockDim.x) {
+        int r = i / LN, c = i % LN;
+        M.A[r][c] = P.A[i];
+        M.W[r][c] = P.W[i];
+        M.QQ[r][c] = P.Q[i] + P.Q[c * LN + r];
+    }
+    for (int i = threadIdx.x; i < LN * LM; i += blockDim.x)
+        M.fu[i / LM][i % LM] = P.dt * P.B[i];
+    for (int i = threadIdx.x; i < LM * LM; i += blockDim.x)
+        M.RR[i / LM][i % LM] = P.R[i] + P.R[(i % LM) * LM + i / LM];
+    for (int i = threadIdx.x; i < LN; i += blockDim.x)
+        M.xg[i] = P.xg[i];
+    for (int i = threadIdx.x; i < LM; i += blockDim.x) {
+        M.ug[i] = P.ug[i];
+        M.lower[i] = P.lower[i];
+        M.upper[i] = P.upper[i];
+    }
+    if (threadIdx.x == 0) {
+        double st = 1.0;
+        for (int t = 0; t < LQ_TAB; ++t) {
+            M.steps[t] = st;
+            st = st * step_dec;
+        }
+    }
+    __syncthreads();
+}
+
+
 // ------------------------------------------------------------------ backward pass
+
+// Diagnostic (ilqr_large_debug_profile): per-wave shader-clock totals of the three phases of a
+// backward step (matrix part 1, boxQP + gains, matrix part 2), 4 uint64 per problem.
+static __device__ unsigned long long* g_large_prof = nullptr;
 
 struct BwOut {
     double dJ1, dJ2;
@@ -379,8 +466,9 @@ struct BwOut {
 
 // _backward_pass + _compute_Q_terms (ilqr_core.py:109-228) for one problem.
 // xs [T+1][32], us [T][8] -> k [T][8], K [T][8][32] (zeros where the sweep does not reach).
-__device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, const double* xs, const double* us,
-                               double mu, double* k, double* K, BwOut& out, int32_t* qp_result, int32_t* free_mask)
+__device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMem& M, WaveMem& S, const double* xs,
+                               const double* us, double mu, double* k, double* K, BwOut& out, int32_t* qp_result,
+                               int32_t* free_mask)
 {
     const LaneId L = lane_id();
     const int T = P.T;
@@ -396,25 +484,16 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
     if (free_mask)
         for (int i = lane; i < T * LM; i += 64)
             free_mask[i] = 0;
-    __syncthreads();
+    wave_sync();
 
-    // constants in N layout
-    d4 QQ[2][2], QQt[2][2], fu[2][1], RR[1][1];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            QQ[rt][ct] = load_n(P.Q, LN, LN, LN, rt, ct, L) + load_nt(P.Q, LN, LN, LN, rt, ct, L);
-            QQt[rt][ct] = load_n(P.Qt, LN, LN, LN, rt, ct, L) + load_nt(P.Qt, LN, LN, LN, rt, ct, L);
-        }
-        fu[rt][0] = P.dt * load_n(P.B, LM, LN, LM, rt, 0, L); // f_u = dt B
-    }
-    RR[0][0] = load_n(P.R, LM, LM, LM, 0, 0, L) + load_nt(P.R, LM, LM, LM, 0, 0, L);
-    d4 xg[2][1], ug[1][1];
-    xg[0][0] = load_v(P.xg, LN, 0, L);
-    xg[1][0] = load_v(P.xg, LN, 1, L);
-    ug[0][0] = load_v(P.ug, LM, 0, L);
-    d4 lowv = load_v(P.lower, LM, 0, L), upv = load_v(P.upper, LM, 0, L);
+    // the model matrices come from LDS where they are used; only the small pieces stay in registers
+    d4 fu[2][1], RR[1][1], xg[2][1], ug[1][1];
+    fu[0][0] = load_n(&M.fu[0][0], LM + 1, LN, LM, 0, 0, L);
+    fu[1][0] = load_n(&M.fu[0][0], LM + 1, LN, LM, 1, 0, L);
+    RR[0][0] = load_n(&M.RR[0][0], LM, LM, LM, 0, 0, L);
+    xg[0][0] = load_v(M.xg, LN, 0, L);
+    xg[1][0] = load_v(M.xg, LN, 1, L);
+    ug[0][0] = load_v(M.ug, LM, 0, L);
 
     // V_x, V_xx = terminal l_x, l_xx (:120-121)
     d4 Vx[2][1], Vxx[2][2];
@@ -422,12 +501,12 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
         d4 xd[2][1];
         xd[0][0] = load_v(xs + (size_t)T * LN, LN, 0, L) - xg[0][0];
         xd[1][0] = load_v(xs + (size_t)T * LN, LN, 1, L) - xg[1][0];
-        mm_tn<2, 2, 1>(QQt, xd, Vx); // l_x[j] = sum_a xd[a] (Q + Q^T)[a][j]
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
-                Vxx[rt][ct] = QQt[rt][ct];
+                Vxx[rt][ct] = load_n(P.Qt, LN, LN, LN, rt, ct, L) + load_nt(P.Qt, LN, LN, LN, rt, ct, L);
+        mm_tn<2, 2, 1>(Vxx, xd, Vx); // l_x[j] = sum_a xd[a] (Q_T + Q_T^T)[a][j]
     }
     out.dJ1 = 0.0;
     out.dJ2 = 0.0;
@@ -435,7 +514,11 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
     out.qp_iter = out.qp_backtrack = out.n_clamped = 0;
     out.rc = 0;
 
+    unsigned long long* prof = g_large_prof;
+    unsigned long long c_p1 = 0, c_qp = 0, c_p2 = 0;
     for (int i = T - 1; i >= 0; --i) {
+        long long t_a = prof ? clock64() : 0;
+        { // ---- matrix part 1: f_x, then what the boxQP needs (Q_u, Q_ux, Q_uu)
         d4 xv[2][1], uv[1][1];
         xv[0][0] = load_v(xs + (size_t)i * LN, LN, 0, L);
         xv[1][0] = load_v(xs + (size_t)i * LN, LN, 1, L);
@@ -449,7 +532,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    WT[rt][ct] = load_nt(P.W, LN, LN, LN, rt, ct, L);
+                    WT[rt][ct] = load_nt(&M.W[0][0], LN + 1, LN, LN, rt, ct, L);
             mm_tn<2, 2, 1>(WT, xv, z);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -462,7 +545,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
                 }
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    d4 An = load_n(P.A, LN, LN, LN, rt, ct, L), Wn = load_n(P.W, LN, LN, LN, rt, ct, L);
+                    d4 An = load_n(&M.A[0][0], LN + 1, LN, LN, rt, ct, L), Wn = load_n(&M.W[0][0], LN + 1, LN, LN, rt, ct, L);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         double id = (16 * rt + L.g + 4 * r == 16 * ct + L.c) ? 1.0 : 0.0;
@@ -471,34 +554,14 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
                 }
             }
         }
-        // l_x, l_u (ilqr_cost.py:555-587)
-        d4 lx[2][1], lu[1][1];
+        // Q_u = l_u + f_u^T V_x                                   (:207, ilqr_cost.py:571-587)
+        d4 Qu[1][1];
         {
-            d4 xd[2][1], ud[1][1];
-            xd[0][0] = xv[0][0] - xg[0][0];
-            xd[1][0] = xv[1][0] - xg[1][0];
+            d4 ud[1][1], lu[1][1];
             ud[0][0] = uv[0][0] - ug[0][0];
-            mm_tn<2, 2, 1>(QQ, xd, lx);
             mm_tn<1, 1, 1, 2>(RR, ud, lu);
-        }
-        // Q_x = l_x + f_x^T V_x ; Q_u = l_u + f_u^T V_x          (:206-207)
-        d4 Qx[2][1], Qu[1][1];
-        mm_tn<2, 2, 1>(fx, Vx, Qx);
-        mm_tn<2, 1, 1>(fu, Vx, Qu);
-        Qx[0][0] = lx[0][0] + Qx[0][0];
-        Qx[1][0] = lx[1][0] + Qx[1][0];
-        Qu[0][0] = lu[0][0] + Qu[0][0];
-        // M1^T = V_xx^T f_x ; Q_xx = l_xx + M1 f_x                (:208)
-        d4 Qxx[2][2];
-        {
-            d4 M1T[2][2];
-            mm_tn<2, 2, 2>(Vxx, fx, M1T);
-            mm_tn<2, 2, 2>(M1T, fx, Qxx);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    Qxx[rt][ct] = QQ[rt][ct] + Qxx[rt][ct];
+            mm_tn<2, 1, 1>(fu, Vx, Qu);
+            Qu[0][0] = lu[0][0] + Qu[0][0];
         }
         // reg = V_xx + mu I ; M2^T = reg^T f_u ; Q_ux = M2 f_x ; Q_uu = l_uu + M2 f_u   (:210-212)
         d4 Qux[1][2], Quu[1][1];
@@ -520,83 +583,130 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
             Qux[0][1] = 0.0 + Qux[0][1];
             Quu[0][0] = RR[0][0] + Quu[0][0];
         }
-        // ---- hand Q_uu, Q_u, Q_ux and the bounds to the scalar part through LDS
-        store_n(S.qp.H, LM, LM, LM, 0, 0, Quu[0][0], L);
-        store_v(S.qp.g, LM, 0, Qu[0][0], L);
-        store_v(S.qp.lo, LM, 0, lowv - uv[0][0], L);
-        store_v(S.qp.hi, LM, 0, upv - uv[0][0], L);
+        // ---- hand Q_uu, Q_u, Q_ux and the bounds to the scalar part through LDS, and park f_x, V_xx,
+        // V_x there as well: the boxQP below needs the registers, and what it does not need
+        // (Q_x, Q_xx) is computed after it
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            store_v(S.vx, LN, rt, Vx[rt][0], L);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                store_n(&S.Vn[0][0], LN + 1, LN, LN, rt, ct, fx[rt][ct], L);
+                store_n(&S.P1[0][0], LN + 1, LN, LN, rt, ct, Vxx[rt][ct], L);
+            }
+        }
+        store_n(S.H, LM, LM, LM, 0, 0, Quu[0][0], L);
+        store_v(S.g, LM, 0, Qu[0][0], L);
+        store_v(S.lo, LM, 0, load_v(M.lower, LM, 0, L) - uv[0][0], L);
+        store_v(S.hi, LM, 0, load_v(M.upper, LM, 0, L) - uv[0][0], L);
         store_n(&S.Qux[0][0], LN + 1, LM, LN, 0, 0, Qux[0][0], L);
         store_n(&S.Qux[0][0], LN + 1, LM, LN, 0, 1, Qux[0][1], L);
-        __syncthreads();
+        wave_sync();
+        }
+        long long t_b = prof ? clock64() : 0;
         // np.all(np.linalg.eigvals(Q_uu) > 0) else print / warn / break   (:137-140)
         bool finite = true;
+#pragma unroll
         for (int a = 0; a < LM * LM; ++a)
-            finite = finite && (fabs(S.qp.H[a]) < __builtin_inf());
+            finite = finite && (fabs(S.H[a]) < __builtin_inf());
         if (!finite) {
             out.rc = 2;
             break;
         }
-        if (lq_chol(LM, S.qp.H, LM, S.qp.Lfull, LM) != 0) {
-            out.stopped_at = i;
-            break;
+        QPR qr;
+        qr.g = S.g;
+        qr.lo = S.lo;
+        qr.hi = S.hi;
+        qr.Lf = S.Lf;
+        {
+            bool all_free[LM];
+#pragma unroll
+            for (int a = 0; a < LM; ++a)
+                all_free[a] = true;
+            if (lr_chol(S.H, all_free, qr.Lf)) {
+                out.stopped_at = i;
+                break;
+            }
+            // k[i] = cho_solve((R_Q_uu, True), Q_u): the (positive-sign) boxQP warm start   (:145)
+#pragma unroll
+            for (int a = 0; a < LM; ++a)
+                qr.x[a] = S.g[a];
+            lr_solve(qr.Lf, all_free, qr.x);
         }
-        // k[i] = cho_solve((R_Q_uu, True), Q_u): the (positive-sign) boxQP warm start   (:145)
-        for (int a = 0; a < LM; ++a)
-            S.qp.x[a] = S.qp.g[a];
-        lq_solve(LM, S.qp.Lfull, LM, S.qp.x);
-        LQPOut qo;
-        lq_boxqp(QO, S.qp, qo);
-        if (qo.linalg) {
+        lr_boxqp(QO, S.H, M.steps, qr);
+        if (qr.linalg) {
             out.rc = 2;
             break;
         }
-        out.qp_iter += qo.n_iter;
-        out.qp_backtrack += qo.n_bt;
-        out.n_clamped += qo.nf < LM ? 1 : 0;
+        out.qp_iter += qr.n_iter;
+        out.qp_backtrack += qr.n_bt;
+        out.n_clamped += qr.nf < LM ? 1 : 0;
         if (qp_result && lane == 0)
-            qp_result[i] = qo.result;
-        if (free_mask && lane < LM)
-            free_mask[(size_t)i * LM + lane] = S.qp.freev[lane];
+            qp_result[i] = qr.result;
+        if (free_mask && lane == 0) {
+#pragma unroll
+            for (int a = 0; a < LM; ++a)
+                free_mask[(size_t)i * LM + a] = qr.fr[a] ? 1 : 0;
+        }
         // K[i, free, :] = -cho_solve((H_ff, True), Q_ux[free, :]); clamped rows stay 0   (:157-160)
         if (lane < LN) {
             double col[LM];
 #pragma unroll
             for (int a = 0; a < LM; ++a)
-                col[a] = a < qo.nf ? S.Qux[S.qp.fidx[a < qo.nf ? a : 0]][lane] : 0.0;
-            // forward and back substitution with the nf x nf factor (row stride 8)
+                col[a] = qr.fr[a] ? S.Qux[a][lane] : 0.0;
+            if (qr.nf > 0)
+                lr_solve(qr.Lf, qr.fr, col);
 #pragma unroll
             for (int a = 0; a < LM; ++a)
-                if (a < qo.nf) {
-                    double s = col[a];
-#pragma unroll
-                    for (int b = 0; b < LM; ++b)
-                        if (b < a)
-                            s = fma(-S.qp.Hff[a * LM + b], col[b], s);
-                    col[a] = s * (1.0 / S.qp.Hff[a * LM + a]);
-                }
-#pragma unroll
-            for (int a = LM - 1; a >= 0; --a)
-                if (a < qo.nf) {
-                    double s = col[a];
-#pragma unroll
-                    for (int b = 0; b < LM; ++b)
-                        if (b > a && b < qo.nf)
-                            s = fma(-S.qp.Hff[b * LM + a], col[b], s);
-                    col[a] = s * (1.0 / S.qp.Hff[a * LM + a]);
-                }
-#pragma unroll
-            for (int a = 0; a < LM; ++a)
-                S.K[a][lane] = 0.0;
-#pragma unroll
-            for (int a = 0; a < LM; ++a)
-                if (a < qo.nf)
-                    S.K[S.qp.fidx[a]][lane] = col[a] * -1;
+                S.K[a][lane] = qr.fr[a] ? col[a] * -1 : 0.0;
         }
-        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < LM; ++a)
+                S.x[a] = qr.x[a];
+        }
+        wave_sync();
+        long long t_c = prof ? clock64() : 0;
+        // ---- back to the matrix part: reload what was parked, then Q_x and Q_xx
+        d4 Qx[2][1], Qxx[2][2];
+        {
+            d4 fx[2][2], QQ[2][2], xd[2][1], lx[2][1];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                Vx[rt][0] = load_v(S.vx, LN, rt, L);
+                xd[rt][0] = load_v(xs + (size_t)i * LN, LN, rt, L) - xg[rt][0];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    fx[rt][ct] = load_n(&S.Vn[0][0], LN + 1, LN, LN, rt, ct, L);
+                    Vxx[rt][ct] = load_n(&S.P1[0][0], LN + 1, LN, LN, rt, ct, L);
+                    QQ[rt][ct] = load_n(&M.QQ[0][0], LN + 1, LN, LN, rt, ct, L);
+                }
+            }
+            wave_sync(); // S.Vn is reused below
+            // l_x (ilqr_cost.py:555-569) ; Q_x = l_x + f_x^T V_x          (:206)
+            mm_tn<2, 2, 1>(QQ, xd, lx);
+            mm_tn<2, 2, 1>(fx, Vx, Qx);
+            Qx[0][0] = lx[0][0] + Qx[0][0];
+            Qx[1][0] = lx[1][0] + Qx[1][0];
+            // M1^T = V_xx^T f_x ; Q_xx = l_xx + M1 f_x                    (:208)
+            d4 M1T[2][2];
+            mm_tn<2, 2, 2>(Vxx, fx, M1T);
+            mm_tn<2, 2, 2>(M1T, fx, Qxx);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    Qxx[rt][ct] = QQ[rt][ct] + Qxx[rt][ct];
+        }
+        d4 Qux[1][2], Quu[1][1], Qu[1][1];
+        Qux[0][0] = load_n(&S.Qux[0][0], LN + 1, LM, LN, 0, 0, L);
+        Qux[0][1] = load_n(&S.Qux[0][0], LN + 1, LM, LN, 0, 1, L);
+        Quu[0][0] = load_n(S.H, LM, LM, LM, 0, 0, L);
+        Qu[0][0] = load_v(S.g, LM, 0, L);
         d4 Kn[1][2], kv[1][1];
         Kn[0][0] = load_n(&S.K[0][0], LN + 1, LM, LN, 0, 0, L);
         Kn[0][1] = load_n(&S.K[0][0], LN + 1, LM, LN, 0, 1, L);
-        kv[0][0] = load_v(S.qp.x, LM, 0, L);
+        kv[0][0] = load_v(S.x, LM, 0, L);
         store_n(K + (size_t)i * LM * LN, LN, LM, LN, 0, 0, Kn[0][0], L);
         store_n(K + (size_t)i * LM * LN, LN, LM, LN, 0, 1, Kn[0][1], L);
         store_v(k + (size_t)i * LM, LM, 0, kv[0][0], L);
@@ -623,7 +733,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
                     store_n(&S.Vn[0][0], LN + 1, LN, LN, rt, ct, vn, L);
                 }
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -634,21 +744,34 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, WaveMem& S, c
         }
         // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)                 (:175-176)
         {
-            const double* kq = S.qp.x;
-            double d1 = kq[0] * S.qp.g[0];
+            const double* kq = S.x;
+            double d1 = kq[0] * S.g[0];
             for (int c = 1; c < LM; ++c)
-                d1 = fma(kq[c], S.qp.g[c], d1);
+                d1 = fma(kq[c], S.g[c], d1);
             double d2 = 0.0;
             for (int a = 0; a < LM; ++a) {
-                double acc = S.qp.H[a * LM] * kq[0];
+                double acc = S.H[a * LM] * kq[0];
                 for (int c = 1; c < LM; ++c)
-                    acc = fma(S.qp.H[a * LM + c], kq[c], acc);
+                    acc = fma(S.H[a * LM + c], kq[c], acc);
                 d2 = (a == 0) ? kq[0] * acc : fma(kq[a], acc, d2);
             }
             out.dJ1 = out.dJ1 + d1;
             out.dJ2 = out.dJ2 + d2 * 0.5;
         }
-        __syncthreads(); // the LDS images are rewritten by the next step
+        wave_sync(); // the LDS images are rewritten by the next step
+        if (prof) {
+            long long t_d = clock64();
+            c_p1 += t_b - t_a;
+            c_qp += t_c - t_b;
+            c_p2 += t_d - t_c;
+        }
+    }
+    if (prof && lane == 0) {
+        int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        prof[w * 4 + 0] = c_p1;
+        prof[w * 4 + 1] = c_qp;
+        prof[w * 4 + 2] = c_p2;
+        prof[w * 4 + 3] = (unsigned long long)T;
     }
 }
 
@@ -767,34 +890,42 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
                 S.J[L.c] = J;
             }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ------------------------------------------------------------------ kernels
 
-__global__ __launch_bounds__(64) void k_large_rollout_cost(LargeP P, int64_t B, const double* x0, const double* us,
+__global__ __launch_bounds__(256) void k_large_rollout_cost(LargeP P, int64_t B, const double* x0, const double* us,
                                                             double* xs, double* J)
 {
-    __shared__ WaveMem S;
-    int64_t b = blockIdx.x;
+    __shared__ BlockMem M;
+    block_init(M, P, 0.5);
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B)
+        return;
+    WaveMem& S = M.wv[threadIdx.x >> 6];
     large_forward<true>(P, S, nullptr, us + b * P.T * LM, nullptr, nullptr, x0 + b * LN, 0.0, 0,
                         xs + b * (P.T + 1) * LN, nullptr);
-    if (threadIdx.x == 0)
+    if ((threadIdx.x & 63) == 0)
         J[b] = S.J[0];
 }
 
-__global__ __launch_bounds__(64) void k_large_backward(LargeP P, LQPOpts QO, int64_t B, const double* xs,
+__global__ __launch_bounds__(256) void k_large_backward(LargeP P, LQPOpts QO, int64_t B, const double* xs,
                                                         const double* us, const double* mu, double* k, double* K,
                                                         double* dJ, int32_t* info, int32_t* qp_result,
                                                         int32_t* free_mask)
 {
-    __shared__ WaveMem S;
-    int64_t b = blockIdx.x;
+    __shared__ BlockMem M;
+    block_init(M, P, QO.step_dec);
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B)
+        return;
+    WaveMem& S = M.wv[threadIdx.x >> 6];
     BwOut o;
-    large_backward(P, QO, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
+    large_backward(P, QO, M, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
                    K + b * P.T * LM * LN, o, qp_result ? qp_result + b * P.T : nullptr,
                    free_mask ? free_mask + b * P.T * LM : nullptr);
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 63) == 0) {
         dJ[b] = o.dJ1;
         dJ[B + b] = o.dJ2;
         info[b] = o.stopped_at;
@@ -810,14 +941,19 @@ struct LAlphas {
 };
 
 // J_new [B][n_alpha]; the trajectory of alpha[store_idx] (if >= 0) goes to xs_new / us_new.
-__global__ __launch_bounds__(64) void k_large_forward_ls(LargeP P, LAlphas al, int n_alpha, int store_idx, int64_t B,
+__global__ __launch_bounds__(256) void k_large_forward_ls(LargeP P, LAlphas al, int n_alpha, int store_idx, int64_t B,
                                                           const double* xs, const double* us, const double* k,
                                                           const double* K, double* J_new, double* xs_new,
                                                           double* us_new)
 {
-    __shared__ WaveMem S;
-    int64_t b = blockIdx.x;
+    __shared__ BlockMem M;
+    block_init(M, P, 0.5);
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B)
+        return;
+    WaveMem& S = M.wv[threadIdx.x >> 6];
     const LaneId L = lane_id();
+    const int lane = threadIdx.x & 63;
     for (int pass = 0; pass * LA < n_alpha; ++pass) {
         int j = pass * LA + L.c;
         double a = j < n_alpha ? al.a[j < 32 ? j : 0] : 0.0;
@@ -825,9 +961,9 @@ __global__ __launch_bounds__(64) void k_large_forward_ls(LargeP P, LAlphas al, i
         large_forward<false>(P, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, k + b * P.T * LM,
                              K + b * P.T * LM * LN, xs + b * (P.T + 1) * LN, a, sc,
                              xs_new ? xs_new + b * (P.T + 1) * LN : nullptr, us_new ? us_new + b * P.T * LM : nullptr);
-        if (threadIdx.x < LA && pass * LA + (int)threadIdx.x < n_alpha)
-            J_new[b * n_alpha + pass * LA + threadIdx.x] = S.J[threadIdx.x];
-        __syncthreads();
+        if (lane < LA && pass * LA + lane < n_alpha)
+            J_new[b * n_alpha + pass * LA + lane] = S.J[lane];
+        wave_sync();
     }
 }
 
@@ -836,17 +972,21 @@ struct LSolveBuf {
 };
 
 // iLQR.update_u (ilqr_core.py:241-399), one problem per wavefront.
-__global__ __launch_bounds__(64) void k_large_solve(LargeP P, LSolveOpts O, int64_t B, const double* x0,
+__global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int64_t B, const double* x0,
                                                      const double* us_init, double* delta_io, double* k0, double* K0,
                                                      double* xs0, double* us0, LSolveBuf W, double* J_out,
                                                      double* mu_out, int32_t* iters_out, int32_t* status_out,
                                                      ilqr_trace tr)
 {
-    __shared__ WaveMem S;
-    const int64_t b = blockIdx.x;
+    __shared__ BlockMem M;
+    block_init(M, P, O.qp.step_dec);
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B)
+        return;
+    WaveMem& S = M.wv[threadIdx.x >> 6];
     const int T = P.T;
     const LaneId L = lane_id();
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     double* xsb[2] = {xs0 + b * (T + 1) * LN, W.xs1 + b * (T + 1) * LN};
     double* usb[2] = {us0 + b * T * LM, W.us1 + b * T * LM};
     double* kb[2] = {k0 + b * T * LM, W.k1 + b * T * LM};
@@ -855,22 +995,22 @@ __global__ __launch_bounds__(64) void k_large_solve(LargeP P, LSolveOpts O, int6
     // us = u_seq_init.copy() ; xs = rollout ; J_opt                     (:269-271)
     for (int i = lane; i < T * LM; i += 64)
         usb[0][i] = us_init[b * T * LM + i];
-    __syncthreads();
+    wave_sync();
     large_forward<true>(P, S, nullptr, usb[0], nullptr, nullptr, x0 + b * LN, 0.0, 0, xsb[0], nullptr);
     double J = S.J[0];
     double mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
     double delta = delta_io[b];
     int status = ILQR_RAN_OUT, iters = 0;
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0; // carried over iterations, as in the reference
-    __syncthreads();
+    wave_sync();
 
     for (int it = 0; it < O.max_iter; ++it) {
         BwOut bw;
         // backward pass with the LinAlgError retry loop (:287-299); when it gives up at mu_max
         // the line search below still runs on the previous gains and Delta_J terms, as in the reference
         for (;;) {
-            large_backward(P, O.qp, S, xsb[cur], usb[cur], mu, kb[gcur ^ 1], Kb[gcur ^ 1], bw, nullptr, nullptr);
-            __syncthreads();
+            large_backward(P, O.qp, M, S, xsb[cur], usb[cur], mu, kb[gcur ^ 1], Kb[gcur ^ 1], bw, nullptr, nullptr);
+            wave_sync();
             if (bw.rc == 0) {
                 gcur ^= 1;
                 dJ1 = bw.dJ1;
@@ -911,7 +1051,7 @@ __global__ __launch_bounds__(64) void k_large_solve(LargeP P, LSolveOpts O, int6
                         break;
                     }
                 }
-                __syncthreads();
+                wave_sync();
                 if (!ended)
                     j = (pass + 1) * LA < O.n_alpha ? (pass + 1) * LA : O.n_alpha;
                 if (accepted && !(pass == 0 && win == 0)) {
@@ -959,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_large_solve(LargeP P, LSolveOpts O, int6
         if (stop || converged)
             break;
     }
-    __syncthreads();
+    wave_sync();
     // results back into the caller's arrays
     if (cur == 1) {
         for (int i = lane; i < (T + 1) * LN; i += 64)
@@ -1025,6 +1165,13 @@ int large_qp(const ilqr_opts* o, LQPOpts& q)
     q.step_dec = o->qp_step_dec;
     q.min_step = o->qp_min_step;
     q.armijo = o->qp_armijo;
+    volatile double step = 1.0;
+    int n = 0;
+    do {
+        step = step * o->qp_step_dec;
+        ++n;
+    } while (!(step < o->qp_min_step) && n < 1000000);
+    q.n_exhaust = n;
     return ILQR_OK;
 }
 
@@ -1043,7 +1190,7 @@ int ilqr_large_rollout_cost(const ilqr_large_model* model, int64_t B, const doub
         return rc;
     if (B < 1 || !x0 || !us || !xs || !J)
         return ILQR_ERR_ARG;
-    hipLaunchKernelGGL(k_large_rollout_cost, dim3((unsigned)B), dim3(64), 0, ls(stream), large_fill(model), B, x0, us,
+    hipLaunchKernelGGL(k_large_rollout_cost, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), B, x0, us,
                        xs, J);
     return lrc(hipGetLastError());
 }
@@ -1061,7 +1208,7 @@ int ilqr_large_backward(const ilqr_large_model* model, const ilqr_opts* opts, in
         return rc;
     if (B < 1 || !xs || !us || !mu || !k || !K || !dJ || !info)
         return ILQR_ERR_ARG;
-    hipLaunchKernelGGL(k_large_backward, dim3((unsigned)B), dim3(64), 0, ls(stream), large_fill(model), q, B, xs, us,
+    hipLaunchKernelGGL(k_large_backward, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), q, B, xs, us,
                        mu, k, K, dJ, info, qp_result, free_mask);
     return lrc(hipGetLastError());
 }
@@ -1080,9 +1227,15 @@ int ilqr_large_forward_ls(const ilqr_large_model* model, int64_t B, int32_t n_al
     LAlphas al;
     for (int i = 0; i < 32; ++i)
         al.a[i] = i < n_alpha ? alphas[i] : 0.0;
-    hipLaunchKernelGGL(k_large_forward_ls, dim3((unsigned)B), dim3(64), 0, ls(stream), large_fill(model), al,
+    hipLaunchKernelGGL(k_large_forward_ls, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), al,
                        (int)n_alpha, (int)store_idx, B, xs, us, k, K, J_new, xs_new, us_new);
     return lrc(hipGetLastError());
+}
+
+int ilqr_large_debug_profile(void* device_buffer)
+{
+    unsigned long long* p = static_cast<unsigned long long*>(device_buffer);
+    return lrc(hipMemcpyToSymbol(HIP_SYMBOL(g_large_prof), &p, sizeof(p)));
 }
 
 size_t ilqr_large_workspace_bytes(const ilqr_large_model* model, int64_t B)
@@ -1136,7 +1289,7 @@ int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opt
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
-    hipLaunchKernelGGL(k_large_solve, dim3((unsigned)B), dim3(64), 0, ls(stream), large_fill(model), O, B, x0, us_init,
+    hipLaunchKernelGGL(k_large_solve, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), O, B, x0, us_init,
                        delta, k, K, xs, us, W, J, mu, iters, status, tr);
     return lrc(hipGetLastError());
 }

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Where a backward step of the large-state path spends its cycles (diagnostic hook)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from ilqr_amd import _hip  # noqa: E402
+from oracle import c_oracle as co  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+T = 200
+dev = torch.device("cuda:0")
+Mo = co.synthetic_model(T=T)
+M = _hip.LargeModel(T, Mo.A, Mo.B, Mo.W, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=Mo.dt,
+                    sig_c=Mo.sig_c)
+x0, us = co.synthetic_batch(B, T=T)
+x0, us = torch.tensor(x0, device=dev), torch.tensor(us, device=dev)
+xs, _ = _hip.large_rollout_cost(M, x0, us)
+mu = torch.ones(B, dtype=torch.float64, device=dev)
+buf = torch.zeros((B, 4), dtype=torch.int64, device=dev)
+_hip.check(_hip.lib().ilqr_large_debug_profile(C.c_void_p(buf.data_ptr())))
+_hip.large_backward(M, _hip.Opts(), xs, us, mu, want_masks=False)
+torch.cuda.synchronize()
+_hip.check(_hip.lib().ilqr_large_debug_profile(None))
+p = buf.cpu().numpy().astype(np.float64)
+per = p[:, :3] / p[:, 3:4]
+print("cycles per backward step, mean over %d problems: matrix part 1 %.0f, boxQP + gains %.0f, matrix part 2 %.0f"
+      % (B, per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean()))
+print("max over problems: %.0f %.0f %.0f" % tuple(per.max(0)))
