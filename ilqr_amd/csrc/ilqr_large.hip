@@ -174,15 +174,17 @@ __device__ __forceinline__ void wave_sync()
 struct QPR {
     double x[LM];
     const double *g, *lo, *hi; // LDS
-    double (*Lf)[LM];          // LDS: masked lower factor of H_ff (all ones until the first factorisation, :36);
-                               // every lane stores the same values and reads back its own stores
+    double Lf[LM][LM];         // masked lower factor of H_ff (all ones until the first factorisation, :36)
+    double rd[LM];             // 1 / Lf[i][i], formed once per factorisation (the bits every solve would form)
+    unsigned fmask;            // free set Lf was computed for (bit i = variable i free)
+    bool factored;             // false: boxQP has not factorised yet, H_ff is still the all-ones matrix of :36
     bool fr[LM];       // free mask of the last classification
     int result, n_iter, n_factor, n_bt, nf;
     bool linalg;
 };
 
 // Lower Cholesky factor of H restricted to the free set; returns true if a free pivot is not > 0.
-__device__ __forceinline__ bool lr_chol(const double* H, const bool (&fr)[LM], double (*Lf)[LM])
+__device__ __forceinline__ bool lr_chol(const double* H, const bool (&fr)[LM], double (&Lf)[LM][LM], double (&rd)[LM])
 {
     bool fail = false;
 #pragma unroll
@@ -195,6 +197,7 @@ __device__ __forceinline__ bool lr_chol(const double* H, const bool (&fr)[LM], d
         double d = sqrt(s);
         double r = 1.0 / d;
         Lf[j][j] = fr[j] ? d : 1.0;
+        rd[j] = fr[j] ? r : 1.0;
 #pragma unroll
         for (int i = j + 1; i < LM; ++i) {
             double t = H[i * LM + j];
@@ -208,7 +211,8 @@ __device__ __forceinline__ bool lr_chol(const double* H, const bool (&fr)[LM], d
 }
 
 // cho_solve on the free set, b = 0 on clamped entries on exit
-__device__ __forceinline__ void lr_solve(const double (*Lf)[LM], const bool (&fr)[LM], double (&b)[LM])
+__device__ __forceinline__ void lr_solve(const double (&Lf)[LM][LM], const double (&rd)[LM], const bool (&fr)[LM],
+                                         double (&b)[LM])
 {
 #pragma unroll
     for (int i = 0; i < LM; ++i) {
@@ -216,7 +220,7 @@ __device__ __forceinline__ void lr_solve(const double (*Lf)[LM], const bool (&fr
 #pragma unroll
         for (int j = 0; j < i; ++j)
             s = fma(-Lf[i][j], b[j], s);
-        b[i] = fr[i] ? s * (1.0 / Lf[i][i]) : 0.0;
+        b[i] = fr[i] ? s * rd[i] : 0.0;
     }
 #pragma unroll
     for (int i = LM - 1; i >= 0; --i) {
@@ -224,7 +228,29 @@ __device__ __forceinline__ void lr_solve(const double (*Lf)[LM], const bool (&fr
 #pragma unroll
         for (int j = i + 1; j < LM; ++j)
             s = fma(-Lf[j][i], b[j], s);
-        b[i] = fr[i] ? s * (1.0 / Lf[i][i]) : 0.0;
+        b[i] = fr[i] ? s * rd[i] : 0.0;
+    }
+}
+
+// cho_solve with the all-ones "factor" H_ff = np.ones((n, n)) of ilqr_boxQP.py:36 (used until the
+// first factorisation, which can only be while nothing is clamped)
+__device__ __forceinline__ void lr_solve_ones(double (&b)[LM])
+{
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+            s = fma(-1.0, b[j], s);
+        b[i] = s * 1.0;
+    }
+#pragma unroll
+    for (int i = LM - 1; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = i + 1; j < LM; ++j)
+            s = fma(-1.0, b[j], s);
+        b[i] = s * 1.0;
     }
 }
 
@@ -247,7 +273,9 @@ __device__ __forceinline__ double lr_value(const double* H, const double* g, con
 }
 
 // H [64] (LDS, finite and positive definite: the caller has checked), steps: the wave's step table.
-// Q.x holds the warm start on entry.
+// On entry Q.x holds the warm start and Q.Lf / Q.rd / Q.fmask the factor of the full H (the caller
+// needed it for the warm start): a factorisation for a free set that Lf already belongs to is not
+// repeated (same inputs, same bits); the reference's counter still counts it.
 __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps, QPR& Q)
 {
     bool cl[LM];
@@ -256,10 +284,8 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
         cl[i] = false;
         Q.fr[i] = false;
         Q.x[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i]);
-#pragma unroll
-        for (int j = 0; j < LM; ++j)
-            Q.Lf[i][j] = 1.0;
     }
+    Q.factored = false;
     double value = lr_value(H, Q.g, Q.x), oldvalue = 0.0;
     int result = -1, n_iter = 0, n_factor = 0, n_bt = 0;
     bool linalg = false;
@@ -292,10 +318,18 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
             break;
         }
         if (iter == 1 || changed) {
-            if (lr_chol(H, Q.fr, Q.Lf)) {
-                linalg = true; // sla.cholesky raises LinAlgError
-                break;
+            unsigned mask = 0;
+#pragma unroll
+            for (int i = 0; i < LM; ++i)
+                mask |= Q.fr[i] ? (1u << i) : 0u;
+            if (mask != Q.fmask) {
+                if (lr_chol(H, Q.fr, Q.Lf, Q.rd)) {
+                    linalg = true; // sla.cholesky raises LinAlgError
+                    break;
+                }
+                Q.fmask = mask;
             }
+            Q.factored = true;
             ++n_factor;
         }
         // sla.norm(grad[free]); dnrm2 of a single element is its magnitude
@@ -328,7 +362,10 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
             }
             rhs[i] = Q.fr[i] ? Q.g[i] + acc : 0.0;
         }
-        lr_solve(Q.Lf, Q.fr, rhs);
+        if (Q.factored)
+            lr_solve(Q.Lf, Q.rd, Q.fr, rhs);
+        else
+            lr_solve_ones(rhs);
 #pragma unroll
         for (int i = 0; i < LM; ++i)
             search[i] = Q.fr[i] ? rhs[i] * -1 - Q.x[i] : 0.0;
@@ -617,13 +654,12 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         qr.g = S.g;
         qr.lo = S.lo;
         qr.hi = S.hi;
-        qr.Lf = S.Lf;
         {
             bool all_free[LM];
 #pragma unroll
             for (int a = 0; a < LM; ++a)
                 all_free[a] = true;
-            if (lr_chol(S.H, all_free, qr.Lf)) {
+            if (lr_chol(S.H, all_free, qr.Lf, qr.rd)) {
                 out.stopped_at = i;
                 break;
             }
@@ -631,7 +667,8 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 #pragma unroll
             for (int a = 0; a < LM; ++a)
                 qr.x[a] = S.g[a];
-            lr_solve(qr.Lf, all_free, qr.x);
+            lr_solve(qr.Lf, qr.rd, all_free, qr.x);
+            qr.fmask = 0xffu;
         }
         lr_boxqp(QO, S.H, M.steps, qr);
         if (qr.linalg) {
@@ -654,8 +691,12 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 #pragma unroll
             for (int a = 0; a < LM; ++a)
                 col[a] = qr.fr[a] ? S.Qux[a][lane] : 0.0;
-            if (qr.nf > 0)
-                lr_solve(qr.Lf, qr.fr, col);
+            if (qr.nf > 0) {
+                if (qr.factored)
+                    lr_solve(qr.Lf, qr.rd, qr.fr, col);
+                else
+                    lr_solve_ones(col);
+            }
 #pragma unroll
             for (int a = 0; a < LM; ++a)
                 S.K[a][lane] = qr.fr[a] ? col[a] * -1 : 0.0;
@@ -746,11 +787,14 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         {
             const double* kq = S.x;
             double d1 = kq[0] * S.g[0];
+#pragma unroll
             for (int c = 1; c < LM; ++c)
                 d1 = fma(kq[c], S.g[c], d1);
             double d2 = 0.0;
+#pragma unroll
             for (int a = 0; a < LM; ++a) {
                 double acc = S.H[a * LM] * kq[0];
+#pragma unroll
                 for (int c = 1; c < LM; ++c)
                     acc = fma(S.H[a * LM + c], kq[c], acc);
                 d2 = (a == 0) ? kq[0] * acc : fma(kq[a], acc, d2);
