@@ -67,8 +67,106 @@ def cpu_baseline(n_problems, threads):
                        "mean %.1f iterations/solve" % (n_problems, B_PER_GPU, dt, float(out["iters"].mean())))
 
 
+def main_large(args):
+    """--workload large: the large-state configuration (synthetic n=32, m=8, T=200, box limits +-1,
+    fp64 MFMA path, one problem per wavefront).  Same contract; the roofline object is flop-based."""
+    import torch
+    import torch.distributed as dist
+    from ilqr_amd import _hip, sharding
+    from oracle import c_oracle as co
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    B, TL, n, m = (args.batch if args.batch != B_PER_GPU else 8192), 200, 32, 8
+    Mo = co.synthetic_model(T=TL)  # the oracle module only supplies the workload definition here
+    M = _hip.LargeModel(TL, Mo.A, Mo.B, Mo.W, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=Mo.dt,
+                        sig_c=Mo.sig_c, device=dev)
+    x0_h, us_h = co.synthetic_batch(B, T=TL, seed_x=5 + 1000 * rank, seed_u=6 + 1000 * rank)
+    x0, us0 = torch.tensor(x0_h, device=dev), torch.tensor(us_h, device=dev)
+    O = _hip.Opts()
+    ws = None
+    res = {}
+
+    def step():
+        nonlocal ws, res
+        res = _hip.large_solve(M, O, x0, us0, workspace=ws)
+        ws = res["workspace"]
+        if world > 1:
+            for name in ("J", "iters", "status", "xs", "us"):
+                sharding.gather_to_root(res[name], [B] * world, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    step_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    iters = res["iters"].cpu().numpy().astype(np.int64)
+    status = res["status"].cpu().numpy()
+    if rank == 0:
+        flop_bw = TL * (4 * n ** 3 + 10 * m * n ** 2 + 6 * m * m * n + m ** 3 / 3.0)
+        flop_fw = TL * (3 * 2 * n * n + 2 * 2 * n * m + 2 * m * m)
+        flops = float(iters.sum()) * (flop_bw + flop_fw)
+        tf = flops / (step_ms * 1e-3) / 1e12
+        line = {
+            "metric": "iLQR solves/sec (batched synthetic n=32 m=8 T=200, fp64)",
+            "value": world * B * args.steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_iteration": elapsed / args.steps * 1e3 / max(int(iters.max()), 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic non-linear system n=32, m=8, T=200, box limits +-1, %d problems per GPU, "
+                                   "<=200 iterations, tol 1e-4, 30-alpha schedule" % B,
+                       "problems_per_gpu": B, "horizon": TL, "parallelism": "batch-sharded x%d" % world,
+                       "mean_iterations_per_solve": float(iters.mean()), "max_iterations": int(iters.max()),
+                       "converged_fraction": float((status == 1).mean())},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "k_large_solve (whole update_u loop, one problem per wavefront)",
+                         "kernel_ms": step_ms,
+                         "note": "algorithmic flops = problem-iterations x (T x 225 kflop backward + T x 7.3 kflop "
+                                 "for the accepted rollout); fp64 MFMA peak = fp64 vector peak on MI355X"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = max(1, min(16, os.cpu_count() or 1))
+            n_cpu = 128
+            t1 = time.perf_counter()
+            co.solve(Mo, co.Opts(), x0_h[:n_cpu], us_h[:n_cpu], nthreads=threads, trace=False)
+            dt = time.perf_counter() - t1
+            line["cpu_baseline"] = dict(value=n_cpu / dt, unit="solves/s", cores=threads, kind="port",
+                                        sample="first %d problems of rank 0, C port of the reference algorithm "
+                                               "(OpenMP over problems), %.1f s wall" % (n_cpu, dt))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=("cartpole", "large"), default="cartpole",
+                    help="cartpole: the benchmark configuration (default); large: synthetic n=32, m=8, T=200")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -76,6 +174,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "large":
+        return main_large(args)
 
     import torch
     import torch.distributed as dist

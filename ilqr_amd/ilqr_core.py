@@ -40,10 +40,10 @@ class iLQR(BaseTrajOptimizer):
         self.N = int(time_steps)
         self.control_limit = control_limit
 
-        if getattr(sys_dynamics, "device_model", None) != "cartpole":
+        if getattr(sys_dynamics, "device_model", None) not in ("cartpole", "sigmoid32"):
             raise NotImplementedError(
                 "iLQR on the GPU needs a dynamics model with a device implementation "
-                "(ilqr_amd.cartpole.CartPoleDynamics); %r evaluates through Python callbacks, which cannot "
+                "(ilqr_amd.cartpole.CartPoleDynamics, ilqr_amd.synthetic.SigmoidLinearDynamics); %r evaluates through Python callbacks, which cannot "
                 "run inside a kernel" % type(sys_dynamics).__name__)
         if not isinstance(cost_func, (QRCost, PathQRCost)):
             raise NotImplementedError("only QRCost and PathQRCost have a device implementation")
@@ -82,6 +82,11 @@ class iLQR(BaseTrajOptimizer):
     # ------------------------------------------------------------------ helpers
     def _model(self):
         d, c = self.dynamics, self.cost
+        if d.device_model == "sigmoid32":
+            if isinstance(c, PathQRCost):
+                raise NotImplementedError("the large-state path implements QRCost only")
+            return _hip.LargeModel(self.N, d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal, self.lower_bound,
+                                   self.upper_bound, dt=d.tau, sig_c=d.sig_c, device=self._device())
         kw = dict(dt=d.tau, mc=d.masscart, mp=d.masspole, l=d.length, g=d.gravity)
         if isinstance(c, PathQRCost):
             x_path, u_path = c.device_paths(self._device())
@@ -120,6 +125,10 @@ class iLQR(BaseTrajOptimizer):
             return t.contiguous().clone()
         return bc(self.delta_, ()), bc(self.k_, (self.N, m)), bc(self.K_, (self.N, m, n))
 
+    def _solve(self, M, O, *args, **kwargs):
+        fn = _hip.large_solve if isinstance(M, _hip.LargeModel) else _hip.solve
+        return fn(M, O, *args, **kwargs)
+
     # ----------------------------------------------------------------- update_u
     def update_u(self, x0, u_seq_init, n_interations=200, tolerance=1e-4, on_iteration=None,
                  line_search_steps=30, scale=0.1, n_iterations=None):
@@ -151,7 +160,7 @@ class iLQR(BaseTrajOptimizer):
                   mu_max=self.mu_max_ if self.mu_max_ else 0.0, delta0=self.delta_0_)
 
         if on_iteration is None:
-            res = _hip.solve(M, _hip.Opts(max_iter=n_interations, **kw), x0_d, us_d, delta=delta, k=k, K=K)
+            res = self._solve(M, _hip.Opts(max_iter=n_interations, **kw), x0_d, us_d, delta=delta, k=k, K=K)
             xs, us, J, mu = res["xs"], res["us"], res["J"], res["mu"]
             iters, status = res["iters"], res["status"]
         else:
@@ -192,7 +201,7 @@ class iLQR(BaseTrajOptimizer):
             if idx.numel() == 0:
                 break
             d_i, k_i, K_i, mu_i = delta[idx].contiguous(), k[idx].contiguous(), K[idx].contiguous(), mu[idx].contiguous()
-            res = _hip.solve(M, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
+            res = self._solve(M, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
                              trace=True)
             acc = res["trace"]["accepted"][0] == 1
             conv = res["status"] == _hip.STATUS_CONVERGED

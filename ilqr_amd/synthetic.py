@@ -1,0 +1,53 @@
+"""Large-state synthetic model of the solve path: 32 states, 8 controls,
+
+    x+ = x + dt (A x + B u + c phi(W x)),     phi(z) = z / sqrt(1 + z^2)   (element-wise),
+
+with box limits |u| <= max_control.  The reference ships no model of this size; this class plays
+the role ``CartPoleDynamics`` (ilqr/cartpole.py) plays for the cart-pole: a ``Dynamics`` whose
+f / f_x / f_u exist as device code (``device_model = "sigmoid32"``), so that ``iLQR`` can solve it
+on the GPU (one problem per wavefront, fp64 MFMA).  f, f_x, f_u below are host-side numpy
+evaluations of the same expressions for inspection; the solver never calls them.
+"""
+import numpy as np
+
+from .ilqr_dynamics import Dynamics
+
+
+class SigmoidLinearDynamics(Dynamics):
+    device_model = "sigmoid32"
+
+    def __init__(self, A, B, W, dt=0.05, sig_c=2.0, max_control=1.0):
+        self.A = np.array(A, dtype=np.float64)
+        self.B = np.array(B, dtype=np.float64)
+        self.W = np.array(W, dtype=np.float64)
+        assert self.A.shape == (32, 32) and self.W.shape == (32, 32) and self.B.shape == (32, 8), \
+            "the device model is built for 32 states and 8 controls"
+        self.tau = float(dt)
+        self.sig_c = float(sig_c)
+        self.upper_bound = np.full(8, float(max_control))
+        self.lower_bound = np.full(8, -float(max_control))
+
+    @property
+    def state_dimension(self):
+        return 32
+
+    @property
+    def control_dimension(self):
+        return 8
+
+    @property
+    def has_hessians(self):
+        return False
+
+    def f(self, x, u, i):
+        z = self.W.dot(x)
+        return x + self.tau * (self.A.dot(x) + self.B.dot(u) + self.sig_c * z / np.sqrt(1.0 + z * z))
+
+    def f_x(self, x, u, i):
+        z = self.W.dot(x)
+        s = 1.0 + z * z
+        g = self.sig_c / (s * np.sqrt(s))
+        return np.eye(32) + self.tau * (self.A + g[:, None] * self.W)
+
+    def f_u(self, x, u, i):
+        return self.tau * self.B

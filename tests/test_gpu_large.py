@@ -100,3 +100,32 @@ def test_large_solve_bit_exact(hip):
         for key in ("J", "accepted", "alpha_idx", "mu", "delta", "qp_iter", "qp_backtrack", "n_clamped", "stopped_at"):
             assert eq(tr[key][b, :it], ref["trace"][key][b, :it]), (b, key)
     assert (ref["trace"]["n_clamped"] > 0).any() and (ref["status"] == 1).any()
+
+
+def test_large_model_through_the_solver_api(hip):
+    """iLQR(SigmoidLinearDynamics(...), QRCost(...), N).update_u on a batch and, with an
+    on_iteration callback, one launch per iteration: both equal the oracle's solve."""
+    from ilqr_amd import QRCost, iLQR
+    from ilqr_amd.synthetic import SigmoidLinearDynamics
+    T, B = 40, 9
+    Mo = co.synthetic_model(T=T)
+    dyn = SigmoidLinearDynamics(Mo.A, Mo.B, Mo.W, dt=Mo.dt, sig_c=Mo.sig_c, max_control=1.0)
+    cost = QRCost(Mo.Q, Mo.R, Q_terminal=Mo.Qt)
+    x0, us0 = co.synthetic_batch(B, T=T, seed_x=13, seed_u=14)
+    ref = co.solve(Mo, co.Opts(max_iter=20), x0, us0, nthreads=8)
+    s = iLQR(dyn, cost, T)
+    xs, us = s.update_u(x0, us0, n_iterations=20)
+    assert xs.shape == (B, T + 1, 32) and eq(xs, ref["xs"]) and eq(us, ref["us"])
+    assert np.array_equal(s.iterations_, ref["iters"]) and eq(s.K_, ref["K"])
+    log = []
+    t = iLQR(dyn, cost, T)
+    xs1, us1 = t.update_u(x0[0], us0[0], n_iterations=20,
+                          on_iteration=lambda it, xs_, us_, J, acc, conv: log.append((it, J, acc, conv)))
+    it_n = int(ref["iters"][0])
+    assert eq(us1, ref["us"][0]) and len(log) == it_n
+    assert eq([l[1] for l in log], ref["trace"]["J"][0, :it_n])
+    # host-side f / f_x of the mirror class agree with the oracle's model
+    f, fx, fu = co.dynamics(Mo, x0[0], us0[0, 0])
+    np.testing.assert_allclose(dyn.f(x0[0], us0[0, 0], 0), f[0], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(dyn.f_x(x0[0], us0[0, 0], 0), fx[0], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(dyn.f_u(x0[0], us0[0, 0], 0), fu[0], rtol=1e-13, atol=1e-13)
