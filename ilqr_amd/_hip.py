@@ -227,10 +227,16 @@ def deriv_bm(M, B, xs_bm, us_bm):
     return out
 
 
-def backward_bm(M, O, B, xs_bm, us_bm, mu, want_masks=True):
+def backward_bm(M, O, B, xs_bm, us_bm, mu, want_masks=True, deriv=None):
+    """deriv: the dict returned by deriv_bm -> the staged sweep that reads the derivative streams."""
     import torch
-    ld = xs_bm.shape[1]
-    dev = xs_bm.device
+    ld = us_bm.shape[1]
+    dev = us_bm.device
+    d_c = None
+    if deriv is not None:
+        d_c = DerivC()
+        for name in ("fx", "fu", "lx", "lu", "lxx", "luu", "lux", "lxT", "lxxT"):
+            setattr(d_c, name, deriv[name].data_ptr())
     k = torch.empty((M.T * M.m, ld), dtype=torch.float64, device=dev)
     K = torch.empty((M.T * M.m * M.n, ld), dtype=torch.float64, device=dev)
     dJ = torch.zeros((2, ld), dtype=torch.float64, device=dev)
@@ -238,7 +244,8 @@ def backward_bm(M, O, B, xs_bm, us_bm, mu, want_masks=True):
     qres = torch.full((M.T, ld), -100, dtype=torch.int32, device=dev) if want_masks else None
     free = torch.zeros((M.T * M.m, ld), dtype=torch.int32, device=dev) if want_masks else None
     check(lib().ilqr_backward_bm(C.byref(M.c), C.byref(O.c), C.c_int64(B), C.c_int64(ld), _ptr(xs_bm),
-                                 _ptr(us_bm), _ptr(_req(mu, torch.float64)), None, _ptr(k), _ptr(K), _ptr(dJ),
+                                 _ptr(us_bm), _ptr(_req(mu, torch.float64)),
+                                 C.byref(d_c) if d_c is not None else None, _ptr(k), _ptr(K), _ptr(dJ),
                                  _ptr(info), _ptr(qres), _ptr(free), _stream()))
     return dict(k=k, K=K, dJ=dJ, info=info, qp_result=qres, free=free)
 

@@ -702,6 +702,11 @@ __device__ __forceinline__ void bw_init(const Cost& C, const double (&xT)[NX], B
     S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
 }
 
+__device__ __forceinline__ int bw_finish(const QPOptsP& QO, const double* tab, const double (&Qx)[NX], double Qu,
+                                         const double (&Qxx)[NX * NX], const double (&Qux)[NX], double Quu, double u,
+                                         double lower, double upper, BwAcc& S, double& k_out, double (&K_out)[NX],
+                                         int& qp_result, bool& qp_free);
+
 // One step i of _backward_pass (ilqr_core.py:127-176) with _compute_Q_terms
 // (:179-228) inlined for the cart-pole sparsity pattern and m = 1.
 // Returns BW_OK (k_out, K_out, S updated), BW_NOT_PD (the reference prints,
@@ -786,7 +791,15 @@ __device__ __forceinline__ int bw_step(const Cost& C, const QPOptsP& QO, const d
         Qux[2 + c] = 0.0 + acc;
     }
     double Quu = C.luu() + fma(M2[4], J.b4, M2[1] * J.b1);
+    return bw_finish(QO, tab, Qx, Qu, Qxx, Qux, Quu, u, lower, upper, S, k_out, K_out, qp_result, qp_free);
+}
 
+// The part of a backward step that follows the Q-terms: PD test, boxQP, gains, value update.
+__device__ __forceinline__ int bw_finish(const QPOptsP& QO, const double* tab, const double (&Qx)[NX], double Qu,
+                                         const double (&Qxx)[NX * NX], const double (&Qux)[NX], double Quu, double u,
+                                         double lower, double upper, BwAcc& S, double& k_out, double (&K_out)[NX],
+                                         int& qp_result, bool& qp_free)
+{
     // np.all(np.linalg.eigvals(Q_uu) > 0), then cholesky   (:137-141)
     if (!(fabs(Quu) < __builtin_inf()))
         return BW_LINALG;
@@ -846,6 +859,81 @@ __device__ __forceinline__ int bw_step(const Cost& C, const QPOptsP& QO, const d
     for (int b = 0; b < NX; ++b)
         K_out[b] = K[b];
     return BW_OK;
+}
+
+// The same step from derivative tensors handed in as dense arrays (the streams a derivative
+// kernel writes): _compute_Q_terms (ilqr_core.py:179-228) with every term of every np.dot,
+// f_x [5][5], f_u [5], l_x [5], l_u, l_xx [5][5], l_uu, l_ux [5].
+__device__ __forceinline__ int bw_step_dense(const QPOptsP& QO, const double* tab, const double (&fx)[NX * NX],
+                                             const double (&fu)[NX], const double (&lx)[NX], double lu,
+                                             const double (&lxx)[NX * NX], double luu, const double (&lux)[NX],
+                                             double u, double mu, double lower, double upper, BwAcc& S,
+                                             double& k_out, double (&K_out)[NX], int& qp_result, bool& qp_free)
+{
+    const double* Vx = S.Vx;
+    const double* Vxx = S.Vxx;
+    double Qx[NX], Qxx[NX * NX], Qux[NX], M1[NX * NX], M2[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        double acc = fx[j] * Vx[0];
+#pragma unroll
+        for (int a = 1; a < NX; ++a)
+            acc = fma(fx[a * NX + j], Vx[a], acc);
+        Qx[j] = lx[j] + acc;
+    }
+    double Qu;
+    {
+        double acc = fu[0] * Vx[0];
+#pragma unroll
+        for (int a = 1; a < NX; ++a)
+            acc = fma(fu[a], Vx[a], acc);
+        Qu = lu + acc;
+    }
+#pragma unroll
+    for (int a = 0; a < NX; ++a)
+#pragma unroll
+        for (int b = 0; b < NX; ++b) {
+            double acc = fx[a] * Vxx[b];
+#pragma unroll
+            for (int c = 1; c < NX; ++c)
+                acc = fma(fx[c * NX + a], Vxx[c * NX + b], acc);
+            M1[a * NX + b] = acc;
+        }
+#pragma unroll
+    for (int a = 0; a < NX; ++a)
+#pragma unroll
+        for (int b = 0; b < NX; ++b) {
+            double acc = M1[a * NX] * fx[b];
+#pragma unroll
+            for (int c = 1; c < NX; ++c)
+                acc = fma(M1[a * NX + c], fx[c * NX + b], acc);
+            Qxx[a * NX + b] = lxx[a * NX + b] + acc;
+        }
+#pragma unroll
+    for (int b = 0; b < NX; ++b) {
+        double acc = fu[0] * (Vxx[b] + mu * (b == 0 ? 1.0 : 0.0));
+#pragma unroll
+        for (int c = 1; c < NX; ++c)
+            acc = fma(fu[c], Vxx[c * NX + b] + mu * (b == c ? 1.0 : 0.0), acc);
+        M2[b] = acc;
+    }
+#pragma unroll
+    for (int b = 0; b < NX; ++b) {
+        double acc = M2[0] * fx[b];
+#pragma unroll
+        for (int c = 1; c < NX; ++c)
+            acc = fma(M2[c], fx[c * NX + b], acc);
+        Qux[b] = lux[b] + acc;
+    }
+    double Quu;
+    {
+        double acc = M2[0] * fu[0];
+#pragma unroll
+        for (int c = 1; c < NX; ++c)
+            acc = fma(M2[c], fu[c], acc);
+        Quu = luu + acc;
+    }
+    return bw_finish(QO, tab, Qx, Qu, Qxx, Qux, Quu, u, lower, upper, S, k_out, K_out, qp_result, qp_free);
 }
 
 // u_new = u + alpha k + K (x_new - x), ilqr_core.py:104 (never clamped)

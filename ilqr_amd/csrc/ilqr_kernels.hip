@@ -346,6 +346,84 @@ __global__ __launch_bounds__(WAVE) void k_backward(CartpoleP mp, QRCostP Cp, QPO
     info[4 * ld + b] = rc;
 }
 
+// The staged variant: the sweep reads the derivative tensors a derivative kernel has written
+// (f_x, f_u, l_x, l_u, l_xx, l_uu, l_ux per step and the terminal l_x, l_xx) instead of
+// evaluating the model: 67 doubles = 536 bytes per (problem, step) streamed from HBM.
+template <bool RECORD>
+__global__ __launch_bounds__(WAVE) void k_backward_staged(QPOptsP QOp, BoundsP bd, int T, int64_t B, int64_t ld,
+                                                          const double* __restrict__ us,
+                                                          const double* __restrict__ mu, ilqr_deriv_bm_t d,
+                                                          double* __restrict__ k, double* __restrict__ K,
+                                                          double* __restrict__ dJ, int32_t* __restrict__ info,
+                                                          int32_t* qp_result_bm, int32_t* free_bm)
+{
+    __shared__ double s_qp_tab[QP_TAB];
+    qp_fill_step_table(s_qp_tab, QOp.step_dec);
+    int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B)
+        return;
+    QPOptsP QO = qp_opts_in_vgprs(QOp);
+    BwAcc S;
+    // V_x, V_xx = terminal l_x, l_xx (ilqr_core.py:120-121)
+    load5(d.lxT, ld, 0, b, S.Vx);
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i)
+        S.Vxx[i] = d.lxxT[(int64_t)i * ld + b];
+    S.dJ1 = 0.0;
+    S.dJ2 = 0.0;
+    S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+    const double m = mu[b];
+    int stopped_at = -1, rc = BW_OK;
+    for (int i = T - 1; i >= 0; --i) {
+        double kk = 0.0, Kr[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        int qres = -100;
+        bool qfree = false;
+        if (rc == BW_OK) {
+            double fx[NX * NX], lxx[NX * NX], fu[NX], lx[NX], lux[NX];
+            int64_t base = (int64_t)i * NX * NX;
+#pragma unroll
+            for (int e = 0; e < NX * NX; ++e) {
+                fx[e] = d.fx[(base + e) * ld + b];
+                lxx[e] = d.lxx[(base + e) * ld + b];
+            }
+            load5(d.fu, ld, (int64_t)i * NX, b, fu);
+            load5(d.lx, ld, (int64_t)i * NX, b, lx);
+            load5(d.lux, ld, (int64_t)i * NX, b, lux);
+            double lu = d.lu[(int64_t)i * ld + b], luu = d.luu[(int64_t)i * ld + b];
+            double u = us[(int64_t)i * ld + b];
+            double kt, Kt[NX];
+            int qr;
+            bool qf;
+            int r = bw_step_dense(QO, s_qp_tab, fx, fu, lx, lu, lxx, luu, lux, u, m, bd.lo, bd.hi, S, kt, Kt, qr, qf);
+            if (r == BW_OK) {
+                kk = kt;
+#pragma unroll
+                for (int a = 0; a < NX; ++a)
+                    Kr[a] = Kt[a];
+                qres = qr;
+                qfree = qf;
+            } else {
+                rc = r;
+                if (r == BW_NOT_PD)
+                    stopped_at = i;
+            }
+        }
+        k[(int64_t)i * ld + b] = kk;
+        store5(K, ld, (int64_t)i * NX, b, Kr);
+        if (RECORD) {
+            qp_result_bm[(int64_t)i * ld + b] = qres;
+            free_bm[(int64_t)i * ld + b] = qfree ? 1 : 0;
+        }
+    }
+    dJ[b] = S.dJ1;
+    dJ[ld + b] = S.dJ2;
+    info[b] = stopped_at;
+    info[ld + b] = S.qp_iter;
+    info[2 * ld + b] = S.qp_backtrack;
+    info[3 * ld + b] = S.n_clamped;
+    info[4 * ld + b] = rc;
+}
+
 // ------------------------------------------------------------- forward pass
 
 // _forward_pass + _trajectory_cost for one (problem, alpha)   (ilqr_core.py:85-107, :230-239).
@@ -1224,10 +1302,30 @@ int ilqr_backward_bm(const ilqr_model* model, const ilqr_opts* opts, int64_t B, 
     int rc = check_model(model);
     if (rc != ILQR_OK)
         return rc;
-    if (deriv != nullptr)
-        return ILQR_ERR_UNSUPPORTED; // the streamed-tensor variant is not built yet
-    if (!xs || !us || !mu || !k || !K || !dJ || !info || B < 1 || ld < B)
+    if (!us || !mu || !k || !K || !dJ || !info || B < 1 || ld < B || (deriv == nullptr && !xs))
         return ILQR_ERR_ARG;
+    if ((qp_result_bm == nullptr) != (free_bm == nullptr))
+        return ILQR_ERR_ARG;
+    if (deriv != nullptr) {
+        if (!deriv->fx || !deriv->fu || !deriv->lx || !deriv->lu || !deriv->lxx || !deriv->luu || !deriv->lux ||
+            !deriv->lxT || !deriv->lxxT)
+            return ILQR_ERR_ARG;
+        QPOptsP qs;
+        rc = fill_qp(opts, qs);
+        if (rc != ILQR_OK)
+            return rc;
+        BoundsP bds;
+        bds.lo = model->lower[0];
+        bds.hi = model->upper[0];
+        dim3 grid_s((unsigned)((B + WAVE - 1) / WAVE));
+        if (qp_result_bm != nullptr)
+            hipLaunchKernelGGL(k_backward_staged<true>, grid_s, dim3(WAVE), 0, as_stream(stream), qs, bds, model->T, B,
+                               ld, us, mu, *deriv, k, K, dJ, info, qp_result_bm, free_bm);
+        else
+            hipLaunchKernelGGL(k_backward_staged<false>, grid_s, dim3(WAVE), 0, as_stream(stream), qs, bds, model->T, B,
+                               ld, us, mu, *deriv, k, K, dJ, info, qp_result_bm, free_bm);
+        return hip_status(hipGetLastError());
+    }
     CartpoleP mp;
     QRCostP C;
     BoundsP bd;

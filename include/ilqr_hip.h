@@ -126,8 +126,9 @@ int ilqr_deriv_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* 
 
 /* iLQR._backward_pass + _compute_Q_terms (ilqr_core.py:109-228) with boxQP inside
  * (ilqr_boxQP.py:9-186), one problem per lane.
- *   mu [B]; deriv: NULL = evaluate derivatives in the kernel, else read the
- *   streams written by ilqr_deriv_bm.
+ *   mu [B]; deriv: NULL = evaluate derivatives in the kernel (the fused sweep the solver
+ *   uses), else read the streams written by ilqr_deriv_bm (the staged sweep; xs_bm may
+ *   then be NULL).
  *   -> k_bm [T*m, ld], K_bm [T*m*n, ld] (zero where the sweep did not reach),
  *      dJ [2, ld] (Delta_J1, Delta_J2),
  *      info [5, ld] int32: stopped_at, qp_iter, qp_backtrack, n_clamped, rc (0 ok, 1 not PD, 2 non-finite Q_uu),

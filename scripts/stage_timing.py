@@ -32,7 +32,12 @@ print("backward      %.3f ms" % timeit(lambda: _hip.backward_bm(M, O, B, xs, us,
 for na in (1, 4, 30):
     al = O.alphas[:na]
     print("forward x%-2d   %.3f ms" % (na, timeit(lambda: _hip.forward_ls_bm(M, B, al, xs, us, bw["k"], bw["K"]))))
-print("deriv stream  %.3f ms" % timeit(lambda: _hip.deriv_bm(M, B, xs, us)))
+t_d = timeit(lambda: _hip.deriv_bm(M, B, xs, us))
+stream_bytes = B * (T * 67 + 30) * 8.0
+print("deriv stream  %.3f ms  (%.2f TB/s written)" % (t_d, stream_bytes / t_d / 1e9))
+dv = _hip.deriv_bm(M, B, xs, us)
+t_s = timeit(lambda: _hip.backward_bm(M, O, B, None, us, mu, want_masks=False, deriv=dv))
+print("backward, staged (reads the derivative streams) %.3f ms  (%.2f TB/s read)" % (t_s, stream_bytes / t_s / 1e9))
 # a converged-ish trajectory: backward pass cost late in the solve
 res = _hip.solve(M, O, torch.tensor(x0_h, device=dev), torch.tensor(us_h, device=dev))
 xs2 = _hip.pack_bm(res["xs"]); us2 = _hip.pack_bm(res["us"]); mu2 = res["mu"].contiguous()

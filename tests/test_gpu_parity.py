@@ -105,6 +105,36 @@ def test_backward_pass_bit_exact(hip, B, T, scale_u, mu):
         assert (ref["n_clamped"] > 0).any()
 
 
+@pytest.mark.parametrize("cost", ["qr", "path"])
+def test_staged_backward_from_derivative_streams(hip, golden_dir, cost):
+    """Three-stage form: the derivative kernel writes f_x, f_u, l_x, ... as HBM streams and the
+    backward sweep reads them back.  Same gains, same boxQP behaviour, bit for bit, as the
+    oracle (and hence as the fused sweep)."""
+    if cost == "qr":
+        B, T = 150, 100
+        Mo, xs, us = _trajectories(B, T, 4.0, 15)
+        M = hip_model(hip, Mo)
+    else:
+        g, Mo, M = pathqr_models(hip, golden_dir)
+        B, T = 90, Mo.T
+        x0 = co.cartpole_batch(B, T=T, seed_x=73, seed_u=74)[0]
+        us = np.random.RandomState(6).uniform(-3, 3, (B, T, 1))
+        xs, _ = co.rollout_cost(Mo, x0, us)
+    mus = np.full(B, 0.5)
+    ref = co.backward(Mo, co.Opts(), xs, us, mus)
+    xs_bm, us_bm = hip.pack_bm(dev(xs)), hip.pack_bm(dev(us))
+    d = hip.deriv_bm(M, B, xs_bm, us_bm)
+    out = hip.backward_bm(M, hip.Opts(), B, None, us_bm, dev(mus), deriv=d)
+    fused = hip.backward_bm(M, hip.Opts(), B, xs_bm, us_bm, dev(mus))
+    for o in (out, fused):
+        assert eq(hip.unpack_bm(o["k"], B, (T, 1)).cpu().numpy(), ref["k"])
+        assert eq(hip.unpack_bm(o["K"], B, (T, 1, 5)).cpu().numpy(), ref["K"])
+        assert eq(o["dJ"].cpu().numpy()[0, :B], ref["dJ1"]) and eq(o["dJ"].cpu().numpy()[1, :B], ref["dJ2"])
+        assert np.array_equal(o["info"].cpu().numpy()[2, :B], ref["qp_backtrack"])
+        assert np.array_equal(o["qp_result"].cpu().numpy()[:, :B].T, ref["qp_result"])
+    assert (ref["n_clamped"] > 0).any()
+
+
 def test_backward_pass_not_pd_break(hip):
     """A large negative terminal weight makes Q_uu lose positive definiteness: the
     reference breaks out of the sweep and leaves the earlier gains zero (ilqr_core.py:137-140)."""
