@@ -47,6 +47,17 @@ def test_argument_checks_need_no_gpu():
                                     None, None) == -2
     assert lib.ilqr_solve_workspace_bytes(ctypes.byref(bad.c), 100) == 0
     assert lib.ilqr_boxqp_batched(ctypes.c_int64(1), ctypes.c_int32(9), *([None] * 13)) == -1
+    # large-state path: dimensions other than 32 / 8 have no kernel; missing arrays are argument errors
+    L = _hip.LargeModelC()
+    L.n, L.m, L.T = 32, 8, 20
+    assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == 0  # null matrices
+    assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -1
+    for name, _ in _hip.LargeModelC._fields_[6:]:
+        setattr(L, name, 4096)  # never dereferenced: the checks below fail first
+    assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == 10 * 8 * (21 * 32 + 20 * 8 + 20 * 8 + 20 * 8 * 32)
+    assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(0), None, None, None, None, None) == -1
+    L.n = 16
+    assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -2
 
 
 def test_reference_import_names():
