@@ -427,6 +427,31 @@ def test_full_size_batch_properties(hip):
     assert np.array_equal(part["iters"].cpu().numpy(), iters[lo:hi])
 
 
+def test_one_gpu_share_of_the_million_problem_configuration(hip):
+    """131072 problems = one GPU's slice of the 8-GPU, 2^20-problem configuration (4-wave
+    workgroups, two rounds of waves per SIMD): the first 16384 are the benchmark batch, so they
+    must come out exactly as in the 16384-problem launch; a sample of the rest is checked
+    against the oracle; returned states must be the rollout of the returned controls."""
+    B = 131072
+    x0, us0 = co.cartpole_batch(B)
+    Mo = co.cartpole_model()
+    M = hip_model(hip, Mo)
+    out = hip.solve(M, hip.Opts(), dev(x0), dev(us0))
+    small = hip.solve(M, hip.Opts(), dev(x0[:16384]), dev(us0[:16384]))
+    torch.cuda.synchronize()
+    iters, J = out["iters"].cpu().numpy(), out["J"].cpu().numpy()
+    assert np.isfinite(J).all() and iters.min() >= 1 and iters.max() <= 200
+    assert eq(small["us"].cpu().numpy(), out["us"][:16384].cpu().numpy())
+    assert np.array_equal(small["iters"].cpu().numpy(), iters[:16384])
+    idx = np.arange(16384 + 5, B, 4099)
+    ref = co.solve(Mo, co.Opts(), x0[idx], us0[idx], nthreads=8, trace=False)
+    assert np.array_equal(ref["iters"], iters[idx]) and eq(ref["J"], J[idx])
+    assert eq(ref["us"], out["us"].cpu().numpy()[idx])
+    xs_bm, J2 = hip.rollout_cost_bm(M, B, hip.pack_bm(out["xs"][:, 0].contiguous()), hip.pack_bm(out["us"]))
+    assert eq(J2.cpu().numpy(), J)
+    assert eq(hip.unpack_bm(xs_bm, B, (101, 5)).cpu().numpy(), out["xs"].cpu().numpy())
+
+
 def test_boxqp1_on_captured_backward_pass_inputs(hip):
     """Every boxQP call (Q_uu, Q_u, bounds, warm start) made by the backward passes of
     real solves, replayed through the in-register m = 1 routine: the early exits that
