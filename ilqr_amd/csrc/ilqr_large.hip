@@ -493,7 +493,8 @@ __device__ void block_init(BlockMem& M, const LargeP& P, double step_dec)
 // ------------------------------------------------------------------ backward pass
 
 // Diagnostic (ilqr_large_debug_profile): per-wave shader-clock totals of the three phases of a
-// backward step (matrix part 1, boxQP + gains, matrix part 2), 4 uint64 per problem.
+// backward step (matrix part 1, boxQP + gains, matrix part 2; then T, warm start, boxQP proper,
+// boxQP iterations, factorisations), 8 uint64 per problem.
 static __device__ unsigned long long* g_large_prof = nullptr;
 
 struct BwOut {
@@ -552,7 +553,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
     out.rc = 0;
 
     unsigned long long* prof = g_large_prof;
-    unsigned long long c_p1 = 0, c_qp = 0, c_p2 = 0;
+    unsigned long long c_p1 = 0, c_qp = 0, c_p2 = 0, c_warm = 0, c_box = 0, c_qpiter = 0, c_fact = 0;
     for (int i = T - 1; i >= 0; --i) {
         long long t_a = prof ? clock64() : 0;
         { // ---- matrix part 1: f_x, then what the boxQP needs (Q_u, Q_ux, Q_uu)
@@ -670,7 +671,9 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
             lr_solve(qr.Lf, qr.rd, all_free, qr.x);
             qr.fmask = 0xffu;
         }
+        long long t_b1 = prof ? clock64() : 0;
         lr_boxqp(QO, S.H, M.steps, qr);
+        long long t_b2 = prof ? clock64() : 0;
         if (qr.linalg) {
             out.rc = 2;
             break;
@@ -807,15 +810,23 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
             long long t_d = clock64();
             c_p1 += t_b - t_a;
             c_qp += t_c - t_b;
+            c_warm += t_b1 - t_b;
+            c_box += t_b2 - t_b1;
+            c_qpiter += qr.n_iter;
+            c_fact += qr.n_factor;
             c_p2 += t_d - t_c;
         }
     }
     if (prof && lane == 0) {
         int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        prof[w * 4 + 0] = c_p1;
-        prof[w * 4 + 1] = c_qp;
-        prof[w * 4 + 2] = c_p2;
-        prof[w * 4 + 3] = (unsigned long long)T;
+        prof[w * 8 + 0] = c_p1;
+        prof[w * 8 + 1] = c_qp;
+        prof[w * 8 + 2] = c_p2;
+        prof[w * 8 + 3] = (unsigned long long)T;
+        prof[w * 8 + 4] = c_warm;
+        prof[w * 8 + 5] = c_box;
+        prof[w * 8 + 6] = c_qpiter;
+        prof[w * 8 + 7] = c_fact;
     }
 }
 

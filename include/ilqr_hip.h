@@ -232,9 +232,9 @@ int ilqr_large_forward_ls(const ilqr_large_model* model, int64_t B, int32_t n_al
                           int32_t store_idx, const double* xs, const double* us, const double* k, const double* K,
                           double* J_new, double* xs_new, double* us_new, void* stream);
 
-/* Diagnostic hook (no counterpart in the reference): with a device buffer of 4 * B uint64 set,
+/* Diagnostic hook (no counterpart in the reference): with a device buffer of 8 * B uint64 set,
  * every backward sweep records per problem the shader-clock totals of its three phases (matrix
- * part 1, boxQP and gains, matrix part 2) and T.  NULL switches it off.  Synchronous. */
+ * part 1, boxQP and gains, matrix part 2), T, and a breakdown of the second phase.  NULL switches it off.  Synchronous. */
 int ilqr_large_debug_profile(void* device_buffer);
 
 /* iLQR.update_u (ilqr_core.py:241-399), arguments as ilqr_solve_batched. */

@@ -21,7 +21,7 @@ x0, us = co.synthetic_batch(B, T=T)
 x0, us = torch.tensor(x0, device=dev), torch.tensor(us, device=dev)
 xs, _ = _hip.large_rollout_cost(M, x0, us)
 mu = torch.ones(B, dtype=torch.float64, device=dev)
-buf = torch.zeros((B, 4), dtype=torch.int64, device=dev)
+buf = torch.zeros((B, 8), dtype=torch.int64, device=dev)
 _hip.check(_hip.lib().ilqr_large_debug_profile(C.c_void_p(buf.data_ptr())))
 _hip.large_backward(M, _hip.Opts(), xs, us, mu, want_masks=False)
 torch.cuda.synchronize()
@@ -31,3 +31,6 @@ per = p[:, :3] / p[:, 3:4]
 print("cycles per backward step, mean over %d problems: matrix part 1 %.0f, boxQP + gains %.0f, matrix part 2 %.0f"
       % (B, per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean()))
 print("max over problems: %.0f %.0f %.0f" % tuple(per.max(0)))
+print("inside the second phase: warm start (factor + solve) %.0f, boxQP proper %.0f cycles per step; %.2f boxQP "
+      "iterations and %.2f factorisations per step" % ((p[:, 4] / p[:, 3]).mean(), (p[:, 5] / p[:, 3]).mean(),
+                                                       (p[:, 6] / p[:, 3]).mean(), (p[:, 7] / p[:, 3]).mean()))
