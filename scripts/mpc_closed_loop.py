@@ -70,6 +70,38 @@ def run(B=4096, steps=200, N=15, initial_n_iterations=200, subsequent_n_iteratio
     return out
 
 
+def run_graphed(B=4096, steps=200, N=15, initial_n_iterations=200, subsequent_n_iterations=10, record=False):
+    """Same loop with the control step replayed from a HIP graph (ilqr_amd.mpc_graph)."""
+    import torch
+    from ilqr_amd import iLQR
+    from ilqr_amd.mpc_graph import GraphedClosedLoop
+    env, dyn, cost = make_problem(N)
+    st_h, us_h = initial_conditions(B, N)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    loop = GraphedClosedLoop(iLQR(dyn, cost, N), env, torch.tensor(st_h, device=dev), torch.tensor(us_h, device=dev),
+                             subsequent_n_iterations=subsequent_n_iterations)
+    states, controls = [torch.tensor(st_h, device=dev)], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, u = loop.first(initial_n_iterations)
+    if record:
+        states.append(st.clone())
+        controls.append(u.clone())
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps - 1):
+        st, u = loop.step()
+        if record:
+            states.append(st.clone())
+            controls.append(u.clone())
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    out = dict(seconds=t2 - t0, seconds_first=t1 - t0, seconds_replayed=t2 - t1, final_state=st.cpu().numpy())
+    if record:
+        out.update(states=torch.stack(states).cpu().numpy(), controls=torch.stack(controls).cpu().numpy())
+    return out
+
+
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
@@ -78,6 +110,10 @@ if __name__ == "__main__":
     th = res["final_state"][:, 2]
     print("closed loops %d, control steps %d: %.3f s  ->  %.0f closed-loop control steps/s (%.2f ms per step of the batch)"
           % (B, steps, res["seconds"], B * steps / res["seconds"], 1e3 * res["seconds"] / steps))
+    g = run_graphed(B=B, steps=steps)
+    print("with the control step replayed from a HIP graph: %.3f ms per step of the batch -> %.0f control steps/s; "
+          "same final states: %s" % (1e3 * g["seconds_replayed"] / (steps - 1), B * (steps - 1) / g["seconds_replayed"],
+                                     bool(np.array_equal(g["final_state"], res["final_state"]))))
     print("mean iterations: first solve %.1f, later %.2f; final theta in [%.2f, %.2f] rad, |x| <= %.2f m"
           % (res["iterations"][0].mean(), res["iterations"][1:].mean(), th.min(), th.max(),
              np.abs(res["final_state"][:, 0]).max()))

@@ -195,6 +195,19 @@ def test_mpc_full_size_closed_loops_on_device():
         n_it = 10
 
 
+def test_graphed_closed_loop_equals_the_eager_controller():
+    """The control step captured once in a HIP graph and replayed: states and applied controls of
+    every step equal those of RecedingHorizonController + set_state, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import mpc_closed_loop as mpc
+    B, steps = 300, 25
+    eager = mpc.run(B=B, steps=steps, record=True)
+    graphed = mpc.run_graphed(B=B, steps=steps, record=True)
+    assert eq(graphed["states"], eager["states"]) and eq(graphed["controls"], eager["controls"])
+
+
 def test_pathqrcost_through_the_solver_api(golden_dir):
     """iLQR(dynamics, PathQRCost(...)) as a user of the reference would write it; single problem
     against the recorded reference run, batch against the oracle."""
