@@ -557,38 +557,38 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
     double value = qp_value1(H, g, x);
     bool h_pd = H > 0.0; // np.all(np.linalg.eigvals(H) > 0) for a 1x1 matrix
 
+    // The main loop (:85-171) is written with a per-lane `active` flag and selects instead of
+    // breaks: lanes leave it at different points (result 4, 6, 5, not PD, 2), and straight-line
+    // predicated code costs far fewer scalar instructions than the exec-mask bookkeeping of
+    // divergent branches.  A lane that has left keeps all its state; the loop ends when no lane
+    // of the wave is active.
+    bool active = true;
+    double grad = 0.0;
     for (int iter = 0; iter < O.max_iter; ++iter) {
-        if (result != -1)
+        if (__ballot(active) == 0ull)
             break;
-        if (iter > 1 && (oldvalue - value) < O.min_rel * fabs(oldvalue) && (oldvalue - value) > 0.0) {
-            result = 4;
-            break;
-        }
-        oldvalue = value;
-        double grad = g + H * x;
+        bool ex4 = active & (iter > 1) & ((oldvalue - value) < O.min_rel * fabs(oldvalue)) & ((oldvalue - value) > 0.0);
+        result = ex4 ? 4 : result;
+        active = active & !ex4;
+        oldvalue = active ? value : oldvalue;
+        grad = active ? g + H * x : grad;
         bool oldclamped = clamped;
-        clamped = ((x == lo) && (grad > 0.0)) || ((x == hi) && (grad < 0.0));
-        free_ = !clamped;
-        if (clamped) {
-            result = 6;
+        bool cl = ((x == lo) & (grad > 0.0)) | ((x == hi) & (grad < 0.0));
+        clamped = active ? cl : clamped;
+        free_ = active ? !cl : free_;
+        bool ex6 = active & cl;
+        result = ex6 ? 6 : result;
+        active = active & !ex6 & h_pd; // not PD: leave with result -1 (:103-105)
+        bool factorize = active & ((iter == 1) | (oldclamped != clamped));
+        hff = factorize ? sqrtH : hff;
+        rdiag = factorize ? rsqrtH : rdiag;
+        n_factor += factorize ? 1 : 0;
+        bool ex5 = active & (fabs(grad) < O.min_grad);
+        result = ex5 ? 5 : result;
+        active = active & !ex5;
+        n_iter += active ? 1 : 0;
+        if (__ballot(active) == 0ull) // typical last pass: every lane has just left
             break;
-        }
-        if (!h_pd) {
-            result = -1;
-            break;
-        }
-        bool factorize = (iter == 1) || (oldclamped != clamped);
-        if (factorize) {
-            hff = sqrtH;
-            rdiag = rsqrtH;
-            ++n_factor;
-        }
-        double gnorm = fabs(grad);
-        if (gnorm < O.min_grad) {
-            result = 5;
-            break;
-        }
-        ++n_iter;
         double rhs = g + 0.0;
         double sol = (rhs * rdiag) * rdiag;
         double search = sol * -1 - x;
@@ -604,7 +604,7 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
         double xc = clamp1(lo, hi, x + step * search);
         double sdotg = (xc - x) * grad;
         double vc = qp_value1(H, g, xc);
-        bool more = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo);
+        bool more = active & quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo);
         if (__ballot(more) != 0ull) {
             double ax = fabs(x), G = fabs(grad), as = fabs(search);
             double gerr = 5e-16 * (fabs(g) + fabs(H * x)); // |computed grad - exact g + H x| stays below this
@@ -662,9 +662,10 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
                 more = quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo) & !ended;
             }
         }
-        n_bt += nstep;
-        x = xc;
-        value = vc;
+        n_bt += active ? nstep : 0;
+        x = active ? xc : x;
+        value = active ? vc : value;
+        active = active & (result == -1);
     }
     out.x = x;
     out.rdiag = rdiag;
