@@ -1,0 +1,666 @@
+// User-defined dynamics for the batched control-limited iLQR solve (single control, up to 8
+// states).  The reference gets its generality from Python callbacks (AutogradDynamics /
+// FiniteDifferenceDynamics, ilqr/ilqr_dynamics.py:94-575), which cannot run inside a kernel;
+// here a model is a small C source with two functions,
+//
+//     ILQR_FN void ilqr_user_f  (const double* p, const double* x, double u, double* out);
+//     ILQR_FN void ilqr_user_jac(const double* p, const double* x, double u, double* fx, double* fu);
+//
+// (f, and f_x [N][N] row-major / f_u [N]) plus  #define ILQR_USER_N  and  ILQR_USER_NP  (number of
+// parameters p), and this file is compiled ONCE PER MODEL around it:
+//
+//     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+//           -DILQR_USER_MODEL='"model.h"' ilqr_user_tu.hip -o libilqr_user_<name>.so
+//
+// The model may call ilqr_sincos(x, &s, &c), ilqr_atan2(y, x), ilqr_sqrt(x): the library's own
+// deterministic functions.  The solver is iLQR.update_u (ilqr_core.py:241-399) with the dense
+// _compute_Q_terms (every term of every np.dot), boxQP and the serial first-hit line search,
+// one problem per lane, arrays batch-minor in a workspace.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/ilqr_hip.h"
+#include "../../include/ilqr_user.h"
+#include "ilqr_device.hpp"
+
+#define ILQR_FN __device__ __forceinline__
+#define ilqr_sincos(x, s, c) ilqr::det_sincos((x), *(s), *(c))
+#define ilqr_atan2(y, x) ilqr::det_atan2((y), (x))
+#define ilqr_sqrt(x) sqrt(x)
+#ifndef ILQR_USER_MODEL
+#error "compile with -DILQR_USER_MODEL='\"path/to/model.h\"'"
+#endif
+#include ILQR_USER_MODEL
+
+namespace {
+
+using namespace ilqr;
+
+constexpr int UN = ILQR_USER_N;
+constexpr int UNP = ILQR_USER_NP > 0 ? ILQR_USER_NP : 1;
+static_assert(UN >= 1 && UN <= 8, "ILQR_USER_N must be between 1 and 8");
+
+struct UParams {
+    double p[UNP];
+};
+struct UCost { // QRCost, ilqr/ilqr_cost.py:490-530, m = 1
+    double Q[UN * UN], Qt[UN * UN], QQ[UN * UN], QQt[UN * UN];
+    double R, RR, xg[UN], ug;
+};
+struct UBounds {
+    double lo, hi;
+};
+
+__device__ __forceinline__ void uload(const double* base, int64_t ld, int64_t row0, int64_t b, double (&v)[UN])
+{
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+        v[i] = base[(row0 + i) * ld + b];
+}
+__device__ __forceinline__ void ustore(double* base, int64_t ld, int64_t row0, int64_t b, const double (&v)[UN])
+{
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+        base[(row0 + i) * ld + b] = v[i];
+}
+
+// (v^T M) . v in the order of x_diff.T.dot(Q).dot(x_diff), ilqr_cost.py:547
+__device__ __forceinline__ double uquad(const double (&v)[UN], const double* M)
+{
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+        double acc = v[0] * M[j];
+#pragma unroll
+        for (int i = 1; i < UN; ++i)
+            acc = fma(v[i], M[i * UN + j], acc);
+        tot = (j == 0) ? acc * v[0] : fma(acc, v[j], tot);
+    }
+    return tot;
+}
+__device__ __forceinline__ double ucost_l(const UCost& C, const double (&x)[UN], double u)
+{
+    double xd[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+        xd[i] = x[i] - C.xg[i];
+    double sx = uquad(xd, C.Q) * 0.5;
+    double ud = u - C.ug;
+    double su = ((ud * C.R) * ud) * 0.5;
+    return sx + su;
+}
+__device__ __forceinline__ double ucost_lT(const UCost& C, const double (&x)[UN])
+{
+    double xd[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+        xd[i] = x[i] - C.xg[i];
+    return uquad(xd, C.Qt) * 0.5;
+}
+__device__ __forceinline__ void ucost_lx(const double* QQ, const UCost& C, const double (&x)[UN], double (&out)[UN])
+{
+    double xd[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+        xd[i] = x[i] - C.xg[i];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+        double acc = xd[0] * QQ[j];
+#pragma unroll
+        for (int a = 1; a < UN; ++a)
+            acc = fma(xd[a], QQ[a * UN + j], acc);
+        out[j] = acc;
+    }
+}
+
+struct UAcc {
+    double Vx[UN], Vxx[UN * UN];
+    double dJ1, dJ2;
+    int qp_iter, qp_backtrack, n_clamped;
+};
+
+// One step of _backward_pass (ilqr_core.py:127-176) with the dense _compute_Q_terms (:179-228).
+__device__ __forceinline__ int ubw_step(const UParams& P, const UCost& C, const QPOptsP& QO, const double* tab,
+                                        const double (&x)[UN], double u, double mu, double lower, double upper,
+                                        UAcc& S, double& k_out, double (&K_out)[UN])
+{
+    double fx[UN * UN], fu[UN], lx[UN];
+    ilqr_user_jac(P.p, x, u, fx, fu);
+    ucost_lx(C.QQ, C, x, lx);
+    double lu = (u - C.ug) * C.RR;
+    const double* Vx = S.Vx;
+    const double* Vxx = S.Vxx;
+    double Qx[UN], Qxx[UN * UN], Qux[UN], M1[UN * UN], M2[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+        double acc = fx[j] * Vx[0];
+#pragma unroll
+        for (int a = 1; a < UN; ++a)
+            acc = fma(fx[a * UN + j], Vx[a], acc);
+        Qx[j] = lx[j] + acc;
+    }
+    double Qu;
+    {
+        double acc = fu[0] * Vx[0];
+#pragma unroll
+        for (int a = 1; a < UN; ++a)
+            acc = fma(fu[a], Vx[a], acc);
+        Qu = lu + acc;
+    }
+#pragma unroll
+    for (int a = 0; a < UN; ++a)
+#pragma unroll
+        for (int b = 0; b < UN; ++b) {
+            double acc = fx[a] * Vxx[b];
+#pragma unroll
+            for (int c = 1; c < UN; ++c)
+                acc = fma(fx[c * UN + a], Vxx[c * UN + b], acc);
+            M1[a * UN + b] = acc;
+        }
+#pragma unroll
+    for (int a = 0; a < UN; ++a)
+#pragma unroll
+        for (int b = 0; b < UN; ++b) {
+            double acc = M1[a * UN] * fx[b];
+#pragma unroll
+            for (int c = 1; c < UN; ++c)
+                acc = fma(M1[a * UN + c], fx[c * UN + b], acc);
+            Qxx[a * UN + b] = C.QQ[a * UN + b] + acc;
+        }
+#pragma unroll
+    for (int b = 0; b < UN; ++b) {
+        double acc = fu[0] * (Vxx[b] + mu * (b == 0 ? 1.0 : 0.0));
+#pragma unroll
+        for (int c = 1; c < UN; ++c)
+            acc = fma(fu[c], Vxx[c * UN + b] + mu * (b == c ? 1.0 : 0.0), acc);
+        M2[b] = acc;
+    }
+#pragma unroll
+    for (int b = 0; b < UN; ++b) {
+        double acc = M2[0] * fx[b];
+#pragma unroll
+        for (int c = 1; c < UN; ++c)
+            acc = fma(M2[c], fx[c * UN + b], acc);
+        Qux[b] = 0.0 + acc;
+    }
+    double Quu;
+    {
+        double acc = M2[0] * fu[0];
+#pragma unroll
+        for (int c = 1; c < UN; ++c)
+            acc = fma(M2[c], fu[c], acc);
+        Quu = C.RR + acc;
+    }
+    // np.all(np.linalg.eigvals(Q_uu) > 0), then cholesky   (:137-141)
+    if (!(fabs(Quu) < __builtin_inf()))
+        return BW_LINALG;
+    if (!(Quu > 0.0))
+        return BW_NOT_PD;
+    double L = sqrt(Quu);
+    double rL = 1.0 / L;
+    double k0 = (Qu * rL) * rL; // the (positive-sign) boxQP warm start (:145)
+    QP1Out qp;
+    boxqp1(QO, tab, Quu, L, rL, Qu, lower - u, upper - u, k0, qp);
+    double kk = qp.x;
+    S.qp_iter += qp.n_iter;
+    S.qp_backtrack += qp.n_backtrack;
+    S.n_clamped += qp.free_ ? 0 : 1;
+    double K[UN], T1[UN], Vn[UN * UN];
+#pragma unroll
+    for (int b = 0; b < UN; ++b) {
+        K[b] = qp.free_ ? ((Qux[b] * qp.rdiag) * qp.rdiag) * -1 : 0.0;
+        T1[b] = K[b] * Quu;
+    }
+#pragma unroll
+    for (int a = 0; a < UN; ++a) {
+        S.Vx[a] = ((Qx[a] + T1[a] * kk) + K[a] * Qu) + Qux[a] * kk;
+#pragma unroll
+        for (int b = 0; b < UN; ++b)
+            Vn[a * UN + b] = ((Qxx[a * UN + b] + T1[a] * K[b]) + K[a] * Qux[b]) + Qux[a] * K[b];
+    }
+#pragma unroll
+    for (int a = 0; a < UN; ++a)
+#pragma unroll
+        for (int b = a; b < UN; ++b) {
+            double v = 0.5 * (Vn[a * UN + b] + Vn[b * UN + a]);
+            S.Vxx[a * UN + b] = v;
+            S.Vxx[b * UN + a] = v;
+        }
+    S.dJ1 = S.dJ1 + kk * Qu;
+    S.dJ2 = S.dJ2 + (kk * (Quu * kk)) * 0.5;
+    k_out = kk;
+#pragma unroll
+    for (int b = 0; b < UN; ++b)
+        K_out[b] = K[b];
+    return BW_OK;
+}
+
+// One backward sweep; gains of the steps it does not reach are zero (np.zeros_like, :118-119).
+__device__ int ubackward(const UParams& P, const UCost& C, const QPOptsP& QO, const double* tab, const UBounds& bd,
+                         int T, int64_t ld, int64_t b, const double* xs, const double* us, double mu, double* k,
+                         double* K, UAcc& S, int& stopped_at)
+{
+    double xT[UN];
+    uload(xs, ld, (int64_t)T * UN, b, xT);
+    ucost_lx(C.QQt, C, xT, S.Vx);
+#pragma unroll
+    for (int i = 0; i < UN * UN; ++i)
+        S.Vxx[i] = C.QQt[i];
+    S.dJ1 = 0.0;
+    S.dJ2 = 0.0;
+    S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+    stopped_at = -1;
+    int rc = BW_OK;
+    for (int i = T - 1; i >= 0; --i) {
+        double kk = 0.0, Kr[UN];
+#pragma unroll
+        for (int a = 0; a < UN; ++a)
+            Kr[a] = 0.0;
+        if (rc == BW_OK) {
+            double x[UN], kt, Kt[UN];
+            uload(xs, ld, (int64_t)i * UN, b, x);
+            double u = us[(int64_t)i * ld + b];
+            int r = ubw_step(P, C, QO, tab, x, u, mu, bd.lo, bd.hi, S, kt, Kt);
+            if (r == BW_OK) {
+                kk = kt;
+#pragma unroll
+                for (int a = 0; a < UN; ++a)
+                    Kr[a] = Kt[a];
+            } else {
+                rc = r;
+                if (r == BW_NOT_PD)
+                    stopped_at = i;
+            }
+        }
+        k[(int64_t)i * ld + b] = kk;
+        ustore(K, ld, (int64_t)i * UN, b, Kr);
+    }
+    return rc;
+}
+
+// _forward_pass + _trajectory_cost (ilqr_core.py:85-107, :230-239); k == nullptr: plain rollout of us.
+__device__ double uforward(const UParams& P, const UCost& C, int T, int64_t ld, int64_t b, const double* xs,
+                           const double* us, const double* k, const double* K, double alpha, const double* x0,
+                           double* xs_new, double* us_new)
+{
+    double xn[UN], xt[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+        xn[i] = x0[(int64_t)i * ld + b];
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double u = us[(int64_t)t * ld + b];
+        double un = u;
+        if (k != nullptr) {
+            double xo[UN], Kr[UN];
+            uload(xs, ld, (int64_t)t * UN, b, xo);
+            uload(K, ld, (int64_t)t * UN, b, Kr);
+            double acc = Kr[0] * (xn[0] - xo[0]);
+#pragma unroll
+            for (int a = 1; a < UN; ++a)
+                acc = fma(Kr[a], xn[a] - xo[a], acc);
+            un = (u + alpha * k[(int64_t)t * ld + b]) + acc; // never clamped (:104)
+        }
+        if (xs_new != nullptr) {
+            ustore(xs_new, ld, (int64_t)t * UN, b, xn);
+            us_new[(int64_t)t * ld + b] = un;
+        }
+        J = J + ucost_l(C, xn, un);
+        ilqr_user_f(P.p, xn, un, xt);
+#pragma unroll
+        for (int a = 0; a < UN; ++a)
+            xn[a] = xt[a];
+    }
+    if (xs_new != nullptr)
+        ustore(xs_new, ld, (int64_t)T * UN, b, xn);
+    return J + ucost_lT(C, xn);
+}
+
+// Workspace of one wavefront's 64 problems: rows of 64 doubles (lane = problem), two copies of
+// everything that is swapped, all in one contiguous tile so that a wave walks its own region.
+struct UWork {
+    double *xs0, *xs1, *us0, *us1, *k0, *k1, *K0, *K1;
+};
+
+__host__ __device__ inline int64_t utile_rows(int64_t T) { return 2 * ((T + 1) * UN + T + T + T * UN); }
+
+__device__ __forceinline__ UWork utile(double* ws, int64_t tile, int64_t T)
+{
+    double* p = ws + tile * utile_rows(T) * 64;
+    UWork W;
+    W.xs0 = p;
+    W.xs1 = W.xs0 + (T + 1) * UN * 64;
+    W.us0 = W.xs1 + (T + 1) * UN * 64;
+    W.us1 = W.us0 + T * 64;
+    W.k0 = W.us1 + T * 64;
+    W.k1 = W.k0 + T * 64;
+    W.K0 = W.k1 + T * 64;
+    W.K1 = W.K0 + T * UN * 64;
+    return W;
+}
+
+constexpr int ULS_PASS = 8;  // problems per cooperative line-search pass
+constexpr int ULS_MAXA = 32; // largest alpha schedule
+
+// iLQR.update_u (ilqr_core.py:241-399), every lane its own problem.  Reference-layout arrays are
+// copied into / out of the wave's workspace tile by the lane itself.
+// Line search (:301-313): every lane rolls out alpha_0 for its own problem; the problems that
+// need more hand their remaining candidates to the whole wave (lane = one (problem, alpha) pair,
+// costs into LDS) and then scan the costs in the reference's order.  A rollout is a pure function
+// of (problem, alpha), so decisions and numbers are those of the serial loop; a rejected
+// iteration costs ~3 rollout times instead of 30.
+__global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C, SolveOptsP O, UBounds bd, int T, int64_t B,
+                                                   double* ws, const double* x0, const double* us_init,
+                                                   double* delta_io, double* k_io, double* K_io, double* xs_out,
+                                                   double* us_out, double* J_out, double* mu_out,
+                                                   int32_t* iters_out, int32_t* status_out, ilqr_trace tr)
+{
+    __shared__ double s_qp_tab[QP_TAB];
+    __shared__ double s_alpha[ULS_MAXA];
+    __shared__ double s_J[ULS_PASS][ULS_MAXA];
+    __shared__ int s_lane[ULS_PASS], s_cur[ULS_PASS], s_gcur[ULS_PASS];
+    const int lane = threadIdx.x;
+    if (lane < ULS_MAXA)
+        s_alpha[lane] = O.alphas[lane];
+    qp_fill_step_table(s_qp_tab, O.qp.step_dec); // ends with the workgroup barrier
+    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = b < B;
+    const UWork W = utile(ws, blockIdx.x, T);
+    const int64_t ld = 64, bl = lane; // row stride and column inside the tile
+#define XS(i) ((i) ? W.xs1 : W.xs0)
+#define US(i) ((i) ? W.us1 : W.us0)
+#define KF(i) ((i) ? W.k1 : W.k0)
+#define KG(i) ((i) ? W.K1 : W.K0)
+    QPOptsP QO = qp_opts_in_vgprs(O.qp);
+    int cur = 0, gcur = 0;
+    double mu = 1.0, delta = 2.0, J = 0.0;
+    if (valid) {
+        for (int i = 0; i < UN; ++i)
+            W.xs0[(int64_t)i * ld + bl] = x0[b * UN + i];
+        for (int t = 0; t < T; ++t) {
+            W.us0[(int64_t)t * ld + bl] = us_init[b * T + t];
+            W.k0[(int64_t)t * ld + bl] = k_io[b * T + t];
+            for (int i = 0; i < UN; ++i)
+                W.K0[((int64_t)t * UN + i) * ld + bl] = K_io[(b * T + t) * UN + i];
+        }
+        mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
+        delta = delta_io[b];
+        // initial rollout and cost (:269-271)
+        J = uforward(P, C, T, ld, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
+    }
+    double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
+    int status = ILQR_RAN_OUT, iters = 0;
+    bool running = valid && O.max_iter > 0;
+    const int n_more = O.n_alpha - 1; // candidates after alpha_0
+    for (int it = 0; it < O.max_iter; ++it) {
+        if (__ballot(running) == 0ull)
+            break;
+        UAcc S;
+        int stopped_at = -1;
+        S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+        int accepted = 0, j = 0;
+        double Jnew = 0.0;
+        const int nxt = cur ^ 1;
+        bool need = false; // the serial loop would go on to alpha_1
+        if (running) {
+            // backward pass with the LinAlgError retry loop (:287-299)
+            for (;;) {
+                int gnew = gcur ^ 1;
+                int rc = ubackward(P, C, QO, s_qp_tab, bd, T, ld, bl, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S,
+                                   stopped_at);
+                if (rc != BW_LINALG) {
+                    gcur = gnew;
+                    dJ1 = S.dJ1;
+                    dJ2 = S.dJ2;
+                    break;
+                }
+                delta = fmax(delta, 1.0) * O.delta0;
+                mu = fmax(O.mu_min, mu * delta);
+                if (O.mu_max != 0.0 && mu >= O.mu_max)
+                    break;
+            }
+            // line search, alpha_0 (:301-313)
+            if (O.n_alpha > 0) {
+                double alpha = s_alpha[0];
+                Jnew = uforward(P, C, T, ld, bl, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
+                double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+                if (expected <= 0.0) {
+                    // reject the whole iteration
+                } else if ((J - Jnew) / expected > O.scale) {
+                    actual = J - Jnew;
+                    accepted = 1;
+                } else {
+                    need = n_more > 0;
+                    j = need ? 1 : O.n_alpha;
+                }
+            }
+        }
+        // remaining alphas of the problems that need them, ULS_PASS problems per pass
+        // (helper lanes read gains another lane of this wave has just stored)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        unsigned long long mask = __ballot(need);
+        bool redo = false; // accepted at some alpha_j, j >= 1: its trajectory still has to be written
+        while (mask != 0ull) {
+            int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            bool mine = need && rank < ULS_PASS;
+            if (mine) {
+                s_lane[rank] = lane;
+                s_cur[rank] = cur;
+                s_gcur[rank] = gcur;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int np = __popcll(mask);
+            np = np < ULS_PASS ? np : ULS_PASS;
+            int nc = np * n_more;
+            for (int q0 = 0; q0 < nc; q0 += 64) {
+                int q = q0 + lane;
+                if (q < nc) {
+                    int fi = q / n_more, jj = 1 + q % n_more;
+                    int64_t pb = s_lane[fi];
+                    int pc = s_cur[fi], pg = s_gcur[fi];
+                    s_J[fi][jj] = uforward(P, C, T, ld, pb, XS(pc), US(pc), KF(pg), KG(pg), s_alpha[jj], XS(pc), nullptr,
+                                           nullptr);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                // the reference's loop from alpha_1 on, on the tabulated costs
+                for (j = 1; j < O.n_alpha; ++j) {
+                    double alpha = s_alpha[j];
+                    Jnew = s_J[rank][j];
+                    double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+                    if (expected <= 0.0) {
+                        break;
+                    } else if ((J - Jnew) / expected > O.scale) {
+                        actual = J - Jnew;
+                        accepted = 1;
+                        redo = true;
+                        break;
+                    }
+                }
+                need = false;
+            }
+            __builtin_amdgcn_wave_barrier();
+            mask = __ballot(need);
+        }
+        if (redo) // the accepted candidate's states and controls (same arithmetic, same bits)
+            Jnew = uforward(P, C, T, ld, bl, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(cur), XS(nxt), US(nxt));
+        if (running) {
+            bool stop = false;
+            int converged = 0;
+            if (accepted) {
+                delta = fmin(1.0, delta) / O.delta0;
+                mu = mu * delta;
+                if (mu <= O.mu_min)
+                    mu = 0.0;
+                J = Jnew;
+                cur = nxt;
+                if (actual < O.tol)
+                    converged = 1;
+            } else {
+                delta = fmax(delta, 1.0) * O.delta0;
+                mu = fmax(O.mu_min, mu * delta);
+                if (O.mu_max != 0.0 && mu >= O.mu_max) {
+                    status = ILQR_MU_MAX;
+                    stop = true;
+                }
+            }
+            int64_t to = (int64_t)it * B + b;
+            if (tr.J) tr.J[to] = J;
+            if (tr.accepted) tr.accepted[to] = accepted;
+            if (tr.alpha_idx) tr.alpha_idx[to] = j;
+            if (tr.mu) tr.mu[to] = mu;
+            if (tr.delta) tr.delta[to] = delta;
+            if (tr.qp_iter) tr.qp_iter[to] = S.qp_iter;
+            if (tr.qp_backtrack) tr.qp_backtrack[to] = S.qp_backtrack;
+            if (tr.n_clamped) tr.n_clamped[to] = S.n_clamped;
+            if (tr.stopped_at) tr.stopped_at[to] = stopped_at;
+            iters = it + 1;
+            if (converged)
+                status = ILQR_CONVERGED;
+            if (stop || converged)
+                running = false;
+        }
+    }
+    if (valid) {
+        const double* xf = XS(cur);
+        const double* uf = US(cur);
+        const double* kf = KF(gcur);
+        const double* Kf = KG(gcur);
+        for (int t = 0; t <= T; ++t)
+            for (int i = 0; i < UN; ++i)
+                xs_out[(b * (T + 1) + t) * UN + i] = xf[((int64_t)t * UN + i) * ld + bl];
+        for (int t = 0; t < T; ++t) {
+            us_out[b * T + t] = uf[(int64_t)t * ld + bl];
+            k_io[b * T + t] = kf[(int64_t)t * ld + bl];
+            for (int i = 0; i < UN; ++i)
+                K_io[(b * T + t) * UN + i] = Kf[((int64_t)t * UN + i) * ld + bl];
+        }
+        delta_io[b] = delta;
+        J_out[b] = J;
+        mu_out[b] = mu;
+        iters_out[b] = iters;
+        status_out[b] = status;
+    }
+#undef XS
+#undef US
+#undef KF
+#undef KG
+}
+
+int ucheck(const ilqr_user_model* m)
+{
+    if (!m)
+        return ILQR_ERR_ARG;
+    if (m->n != UN || m->m != 1 || m->n_params != ILQR_USER_NP)
+        return ILQR_ERR_UNSUPPORTED;
+    if (m->T < 1 || !m->Q || !m->R || !m->lower || !m->upper || (ILQR_USER_NP > 0 && !m->params))
+        return ILQR_ERR_ARG;
+    return ILQR_OK;
+}
+
+int64_t uld(int64_t B) { return (B + 63) / 64 * 64; }
+
+} // namespace
+
+extern "C" {
+
+int ilqr_user_dims(int32_t* n, int32_t* n_params)
+{
+    if (n)
+        *n = UN;
+    if (n_params)
+        *n_params = ILQR_USER_NP;
+    return ILQR_OK;
+}
+
+size_t ilqr_user_workspace_bytes(const ilqr_user_model* model, int64_t B)
+{
+    if (ucheck(model) != ILQR_OK || B < 1)
+        return 0;
+    int64_t T = model->T;
+    return (size_t)uld(B) * sizeof(double) * (size_t)utile_rows(T);
+}
+
+int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                            const double* us_init, double* delta, double* k, double* K, double* xs, double* us,
+                            double* J, double* mu, int32_t* iters, int32_t* status, const ilqr_trace* trace,
+                            void* workspace, size_t workspace_bytes, void* stream)
+{
+    int rc = ucheck(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (!opts || !opts->alphas || opts->n_alpha < 0 || opts->n_alpha > 32 || opts->max_iter < 0 ||
+        opts->qp_max_iter < 0 || !(opts->qp_step_dec > 0.0) || !(opts->qp_step_dec < 1.0) || !(opts->qp_min_step > 0.0))
+        return ILQR_ERR_ARG;
+    if (B < 1 || !x0 || !us_init || !delta || !k || !K || !xs || !us || !J || !mu || !iters || !status || !workspace)
+        return ILQR_ERR_ARG;
+    if (workspace_bytes < ilqr_user_workspace_bytes(model, B))
+        return ILQR_ERR_WORKSPACE;
+    UParams P;
+    for (int i = 0; i < UNP; ++i)
+        P.p[i] = i < ILQR_USER_NP ? model->params[i] : 0.0;
+    UCost C;
+    const double* Qt = model->Q_terminal ? model->Q_terminal : model->Q;
+    for (int a = 0; a < UN; ++a) {
+        for (int b = 0; b < UN; ++b) {
+            C.Q[a * UN + b] = model->Q[a * UN + b];
+            C.Qt[a * UN + b] = Qt[a * UN + b];
+            C.QQ[a * UN + b] = model->Q[a * UN + b] + model->Q[b * UN + a];
+            C.QQt[a * UN + b] = Qt[a * UN + b] + Qt[b * UN + a];
+        }
+        C.xg[a] = model->x_goal ? model->x_goal[a] : 0.0;
+    }
+    C.R = model->R[0];
+    C.RR = model->R[0] + model->R[0];
+    C.ug = model->u_goal ? model->u_goal[0] : 0.0;
+    UBounds bd;
+    bd.lo = model->lower[0];
+    bd.hi = model->upper[0];
+    SolveOptsP O;
+    O.max_iter = opts->max_iter;
+    O.n_alpha = opts->n_alpha;
+    O.mu_from_array = (opts->mu_init >= 0.0) ? 1 : 0;
+    O.tol = opts->tol;
+    O.scale = opts->scale;
+    O.mu_min = opts->mu_min;
+    O.mu_max = opts->mu_max;
+    O.delta0 = opts->delta0;
+    for (int i = 0; i < 32; ++i)
+        O.alphas[i] = i < opts->n_alpha ? opts->alphas[i] : 0.0;
+    O.qp.max_iter = opts->qp_max_iter;
+    O.qp.min_grad = opts->qp_min_grad;
+    O.qp.min_rel = opts->qp_min_rel_improve;
+    O.qp.step_dec = opts->qp_step_dec;
+    O.qp.min_step = opts->qp_min_step;
+    O.qp.armijo = opts->qp_armijo;
+    {
+        volatile double step = 1.0;
+        int n = 0;
+        do {
+            step = step * opts->qp_step_dec;
+            ++n;
+        } while (!(step < opts->qp_min_step) && n < 1000000);
+        O.qp.n_exhaust = n;
+        O.qp.step_last = step;
+        O.qp.tab_n = n < QP_TAB ? n : QP_TAB;
+        O.qp.inv_log2_dec = (float)(1.0 / std::log2(opts->qp_step_dec));
+    }
+    int64_t T = model->T;
+    ilqr_trace tr;
+    if (trace)
+        tr = *trace;
+    else
+        std::memset(&tr, 0, sizeof(tr));
+    hipLaunchKernelGGL(k_user_solve, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                       P, C, O, bd, (int)T, B, static_cast<double*>(workspace), x0, us_init, delta, k, K, xs, us, J, mu,
+                       iters, status, tr);
+    return hipGetLastError() == hipSuccess ? ILQR_OK : ILQR_ERR_HIP;
+}
+
+} // extern "C"

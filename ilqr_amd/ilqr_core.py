@@ -40,7 +40,7 @@ class iLQR(BaseTrajOptimizer):
         self.N = int(time_steps)
         self.control_limit = control_limit
 
-        if getattr(sys_dynamics, "device_model", None) not in ("cartpole", "sigmoid32"):
+        if getattr(sys_dynamics, "device_model", None) not in ("cartpole", "sigmoid32", "user"):
             raise NotImplementedError(
                 "iLQR on the GPU needs a dynamics model with a device implementation "
                 "(ilqr_amd.cartpole.CartPoleDynamics, ilqr_amd.synthetic.SigmoidLinearDynamics); %r evaluates through Python callbacks, which cannot "
@@ -82,6 +82,12 @@ class iLQR(BaseTrajOptimizer):
     # ------------------------------------------------------------------ helpers
     def _model(self):
         d, c = self.dynamics, self.cost
+        if d.device_model == "user":
+            from . import user_model
+            if isinstance(c, PathQRCost):
+                raise NotImplementedError("user models implement QRCost only")
+            return user_model.UserModel(d.lib, self.N, d.params, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal,
+                                        self.lower_bound, self.upper_bound)
         if d.device_model == "sigmoid32":
             if isinstance(c, PathQRCost):
                 raise NotImplementedError("the large-state path implements QRCost only")
@@ -126,8 +132,12 @@ class iLQR(BaseTrajOptimizer):
         return bc(self.delta_, ()), bc(self.k_, (self.N, m)), bc(self.K_, (self.N, m, n))
 
     def _solve(self, M, O, *args, **kwargs):
-        fn = _hip.large_solve if isinstance(M, _hip.LargeModel) else _hip.solve
-        return fn(M, O, *args, **kwargs)
+        if isinstance(M, _hip.LargeModel):
+            return _hip.large_solve(M, O, *args, **kwargs)
+        if not isinstance(M, _hip.Model):
+            from . import user_model
+            return user_model.solve(M, O, *args, **kwargs)
+        return _hip.solve(M, O, *args, **kwargs)
 
     # ----------------------------------------------------------------- update_u
     def update_u(self, x0, u_seq_init, n_interations=200, tolerance=1e-4, on_iteration=None,

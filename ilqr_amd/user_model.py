@@ -1,0 +1,146 @@
+"""User-defined dynamics on the GPU path (single control, up to 8 states).
+
+The reference takes any Python object with f / f_x / f_u (``AutogradDynamics``,
+``FiniteDifferenceDynamics``, ilqr/ilqr_dynamics.py:94-575).  Python callbacks cannot run inside a
+kernel; here the model is a small C source (see include/ilqr_user.h for the contract) and the
+solver kernels are compiled around it with hipcc, once per model, into
+``ilqr_amd/libilqr_user_<name>.so``.  ``UserDynamics`` wraps that library as a ``Dynamics`` that
+``iLQR`` accepts.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _hip
+from .ilqr_dynamics import Dynamics
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_TU = os.path.join(_HERE, "csrc", "ilqr_user_tu.hip")
+_DEPS = [_TU, os.path.join(_HERE, "csrc", "ilqr_device.hpp"), os.path.join(_HERE, "csrc", "ilqr_math.hpp"),
+         os.path.join(os.path.dirname(_HERE), "include", "ilqr_user.h"),
+         os.path.join(os.path.dirname(_HERE), "include", "ilqr_hip.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+class UserModelC(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("n_params", C.c_int32)] + \
+               [(k, C.POINTER(C.c_double)) for k in ("params", "Q", "R", "Q_terminal", "x_goal", "u_goal", "lower",
+                                                     "upper")]
+
+
+def library_path(name):
+    return os.path.join(_HERE, "libilqr_user_%s.so" % name)
+
+
+def build_user_model(header, name, force=False):
+    """Compile the solver around the model header ``header`` (hipcc, gfx950; needs no GPU)."""
+    header = os.path.abspath(header)
+    out = library_path(name)
+    if (not force and os.path.exists(out)
+            and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in _DEPS + [header])):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc] + HIPCC_FLAGS + ["-DILQR_USER_MODEL=\"%s\"" % header, _TU, "-o", out], check=True)
+    return out
+
+
+class UserModel(object):
+    """ctypes view of one per-model library + the host arrays of one problem family."""
+
+    def __init__(self, lib, T, params, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None):
+        n, npar = C.c_int32(), C.c_int32()
+        _hip.check(lib.ilqr_user_dims(C.byref(n), C.byref(npar)))
+        self.lib, self.n, self.m, self.T = lib, n.value, 1, int(T)
+        host = _hip._host
+        self.a = dict(params=host(params, (npar.value,)), Q=host(Q, (self.n, self.n)), R=host(R, (1, 1)),
+                      Q_terminal=host(Q if Q_terminal is None else Q_terminal, (self.n, self.n)),
+                      x_goal=host(np.zeros(self.n) if x_goal is None else x_goal, (self.n,)),
+                      u_goal=host(np.zeros(1) if u_goal is None else u_goal, (1,)),
+                      lower=host(lower, (1,)), upper=host(upper, (1,)))
+        c = UserModelC()
+        c.n, c.m, c.T, c.n_params = self.n, 1, int(T), npar.value
+        for k, v in self.a.items():
+            setattr(c, k, v.ctypes.data_as(C.POINTER(C.c_double)))
+        self.c = c
+
+
+def load(name):
+    path = library_path(name)
+    if not os.path.exists(path):
+        raise _hip.IlqrHipError("%s is missing: build it with ilqr_amd.user_model.build_user_model(header, %r)"
+                                % (path, name))
+    lib = C.CDLL(path)
+    lib.ilqr_user_workspace_bytes.restype = C.c_size_t
+    lib.ilqr_user_workspace_bytes.argtypes = [C.POINTER(UserModelC), C.c_int64]
+    return lib
+
+
+def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, mu=None):
+    """ilqr_user_solve_batched on reference-layout device tensors (same dict as _hip.solve)."""
+    import torch
+    B, dev = x0.shape[0], x0.device
+    T, n = M.T, M.n
+    f64 = torch.float64
+    delta = torch.full((B,), 2.0, dtype=f64, device=dev) if delta is None else delta
+    k = torch.zeros((B, T, 1), dtype=f64, device=dev) if k is None else k
+    K = torch.zeros((B, T, 1, n), dtype=f64, device=dev) if K is None else K
+    res = dict(xs=torch.empty((B, T + 1, n), dtype=f64, device=dev), us=torch.empty((B, T, 1), dtype=f64, device=dev),
+               J=torch.empty(B, dtype=f64, device=dev), mu=torch.ones(B, dtype=f64, device=dev) if mu is None else mu,
+               iters=torch.empty(B, dtype=torch.int32, device=dev), status=torch.empty(B, dtype=torch.int32, device=dev))
+    need = int(M.lib.ilqr_user_workspace_bytes(C.byref(M.c), C.c_int64(B)))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    tr_c, tr = None, None
+    if trace:
+        tr, tr_c = {}, _hip.TraceC()
+        for name, dt in _hip.TRACE_FIELDS:
+            t = (torch.full((O.max_iter, B), float("nan"), dtype=f64, device=dev) if dt == "f8"
+                 else torch.full((O.max_iter, B), -1, dtype=torch.int32, device=dev))
+            tr[name] = t
+            setattr(tr_c, name, t.data_ptr())
+    p, req = _hip._ptr, _hip._req
+    _hip.check(M.lib.ilqr_user_solve_batched(
+        C.byref(M.c), C.byref(O.c), C.c_int64(B), p(req(x0.reshape(B, n), f64)), p(req(us_init.reshape(B, T, 1), f64)),
+        p(req(delta, f64)), p(req(k, f64)), p(req(K, f64)), p(res["xs"]), p(res["us"]), p(res["J"]), p(res["mu"]),
+        p(res["iters"]), p(res["status"]), C.byref(tr_c) if tr_c is not None else None, p(workspace),
+        C.c_size_t(workspace.numel()), _hip._stream()))
+    res.update(delta=delta, k=k, K=K, trace=tr, workspace=workspace)
+    return res
+
+
+class UserDynamics(Dynamics):
+    """A ``Dynamics`` backed by a per-model device library.
+
+    name: the library built by ``build_user_model(header, name)``; params: the model's parameter
+    vector p; max_control: |u| <= max_control (``lower_bound`` / ``upper_bound``, as CartPoleDynamics)."""
+
+    device_model = "user"
+
+    def __init__(self, name, params, max_control):
+        self.name = name
+        self.lib = load(name)
+        n, npar = C.c_int32(), C.c_int32()
+        _hip.check(self.lib.ilqr_user_dims(C.byref(n), C.byref(npar)))
+        self._n = n.value
+        self.params = np.asarray(params, dtype=np.float64).reshape(npar.value)
+        self.upper_bound = np.array([float(max_control)])
+        self.lower_bound = np.array([-float(max_control)])
+
+    @property
+    def state_dimension(self):
+        return self._n
+
+    @property
+    def control_dimension(self):
+        return 1
+
+    @property
+    def has_hessians(self):
+        return False
+
+    def f(self, x, u, i):
+        raise NotImplementedError("point evaluations of a user model are not exported by its library")
+
+    f_x = f_u = f

@@ -1,0 +1,53 @@
+/* C ABI of a per-model library for USER-DEFINED dynamics (single control, up to 8 states).
+ *
+ * The reference accepts any Python object with f / f_x / f_u (AutogradDynamics,
+ * FiniteDifferenceDynamics: ilqr/ilqr_dynamics.py:94-575) and calls it once per time step.
+ * Callbacks cannot run inside a kernel, so here a model is a small C source ("model header")
+ *
+ *     #define ILQR_USER_N  <states, 1..8>
+ *     #define ILQR_USER_NP <number of double parameters p>
+ *     ILQR_FN void ilqr_user_f  (const double* p, const double* x, double u, double* out);
+ *     ILQR_FN void ilqr_user_jac(const double* p, const double* x, double u,
+ *                                double* fx, double* fu);   (fx: [N][N] row-major, fu: [N])
+ *
+ * that may use ilqr_sincos(x, &s, &c), ilqr_atan2(y, x), ilqr_sqrt(x) and plain arithmetic;
+ * ilqr_amd/csrc/ilqr_user_tu.hip is compiled around it into one shared library per model
+ * (ilqr_amd.user_model.build_user_model does that with hipcc).  That library exports the
+ * functions below; everything else (options, trace, array layouts, per-problem status)
+ * is as for ilqr_solve_batched in ilqr_hip.h. */
+#ifndef ILQR_USER_H
+#define ILQR_USER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ilqr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Model parameters + QRCost (ilqr/ilqr_cost.py:490-530) + control bounds; HOST pointers. */
+typedef struct ilqr_user_model {
+    int32_t n, m, T;    /* n must equal the library's ILQR_USER_N, m must be 1 */
+    int32_t n_params;   /* must equal ILQR_USER_NP */
+    const double* params;             /* [n_params] */
+    const double *Q, *R, *Q_terminal; /* [n*n], [1], [n*n] (Q_terminal NULL = Q) */
+    const double *x_goal, *u_goal;    /* [n], [1] (NULL = zeros) */
+    const double *lower, *upper;      /* [1] */
+} ilqr_user_model;
+
+/* The dimensions the library was compiled for. */
+int ilqr_user_dims(int32_t* n, int32_t* n_params);
+
+/* iLQR.update_u (ilqr_core.py:241-399) for B problems; arguments as ilqr_solve_batched. */
+size_t ilqr_user_workspace_bytes(const ilqr_user_model* model, int64_t B);
+int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                            const double* us_init, double* delta, double* k, double* K, double* xs, double* us,
+                            double* J, double* mu, int32_t* iters, int32_t* status, const ilqr_trace* trace,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILQR_USER_H */

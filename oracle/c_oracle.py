@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
-MODEL_CARTPOLE, MODEL_LINEAR, MODEL_SIGMOID = 0, 1, 2
+MODEL_CARTPOLE, MODEL_LINEAR, MODEL_SIGMOID, MODEL_USER = 0, 1, 2, 3
 COST_QR, COST_PATHQR = 0, 1
 MATH_LIBM, MATH_DET = 0, 1
 
@@ -32,6 +32,7 @@ class _ModelC(C.Structure):
         ("A", _dp), ("B", _dp), ("Q", _dp), ("R", _dp), ("Qt", _dp),
         ("x_goal", _dp), ("u_goal", _dp), ("lower", _dp), ("upper", _dp),
         ("W", _dp), ("sig_c", C.c_double),
+        ("user_f", C.c_void_p), ("user_jac", C.c_void_p), ("user_p", _dp),
     ]
 
 
@@ -89,7 +90,7 @@ class Model:
     def __init__(self, model=MODEL_CARTPOLE, n=5, m=1, T=100, cost_kind=COST_QR, math_mode=MATH_DET,
                  control_limit=True, dt=0.05, mc=1.0, mp=0.1, l=1.0, g=9.8, A=None, B=None,
                  Q=None, R=None, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
-                 W=None, sig_c=0.0):
+                 W=None, sig_c=0.0, user=None, user_params=None):
         self.n, self.m, self.T = n, m, T
         self.model, self.cost_kind, self.math_mode = model, cost_kind, math_mode
         self.control_limit = bool(control_limit)
@@ -115,6 +116,11 @@ class Model:
         c.dt, c.mc, c.mp, c.l, c.g = dt, mc, mp, l, g
         c.A, c.B = _p(self.A), _p(self.B)
         c.W, c.sig_c = _p(self.W), self.sig_c
+        if user is not None:  # (ctypes library of a user model, see build_user_model)
+            self.user, self.user_params = user, _f64(user_params)
+            c.user_f = C.cast(user.user_model_f, C.c_void_p)
+            c.user_jac = C.cast(user.user_model_jac, C.c_void_p)
+            c.user_p = _p(self.user_params)
         c.Q, c.R, c.Qt = _p(self.Q), _p(self.R), _p(self.Qt)
         c.x_goal, c.u_goal = _p(self.x_goal), _p(self.u_goal)
         c.lower, c.upper = _p(self.lower), _p(self.upper)
@@ -333,3 +339,21 @@ def synthetic_batch(B, n=32, m=8, T=200, seed_x=5, seed_u=6):
     x0 = np.random.RandomState(seed_x).uniform(-1.0, 1.0, (B, n))
     us = np.random.RandomState(seed_u).uniform(-0.5, 0.5, (B, T, m))
     return x0, us
+
+
+def build_user_model(header, name):
+    """Compile a user model header for the CPU (oracle/user_model_shim.c) and load it."""
+    header = os.path.abspath(header)
+    out = os.path.join(_HERE, "libusermodel_%s.so" % name)
+    shim = os.path.join(_HERE, "user_model_shim.c")
+    if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in (header, shim))):
+        subprocess.run(["gcc", "-O2", "-mfma", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-shared",
+                        "-DILQR_USER_MODEL=\"%s\"" % header, "-I", _HERE, shim, "-o", out, "-lm"], check=True)
+    return C.CDLL(out)
+
+
+def user_model(lib_user, params, T, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None):
+    n = lib_user.user_model_n()
+    assert lib_user.user_model_np() == len(params)
+    return Model(MODEL_USER, n, 1, T, COST_QR, MATH_DET, True, Q=Q, R=R, Q_terminal=Q_terminal, x_goal=x_goal,
+                 u_goal=u_goal, lower=lower, upper=upper, user=lib_user, user_params=params)

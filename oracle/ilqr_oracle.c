@@ -45,7 +45,12 @@
 #define NMAX 32
 #define MMAX 8
 
-enum { MODEL_CARTPOLE = 0, MODEL_LINEAR = 1, MODEL_SIGMOID = 2 };
+enum { MODEL_CARTPOLE = 0, MODEL_LINEAR = 1, MODEL_SIGMOID = 2, MODEL_USER = 3 };
+
+/* A user-supplied model (single control): the same source the device library is built from,
+ * compiled for the CPU (oracle/user_model_shim.c). */
+typedef void (*user_f_fn)(const double *p, const double *x, double u, double *out);
+typedef void (*user_jac_fn)(const double *p, const double *x, double u, double *fx, double *fu);
 enum { COST_QR = 0, COST_PATHQR = 1 };
 enum { MATH_LIBM = 0, MATH_DET = 1 };
 
@@ -62,6 +67,9 @@ typedef struct {
      * applied element-wise.  W [n*n], c = sig_c, dt as above. */
     const double *W;
     double sig_c;
+    user_f_fn user_f;       /* MODEL_USER */
+    user_jac_fn user_jac;
+    const double *user_p;   /* its parameters */
     const double *Q, *R, *Qt;  /* [n*n], [m*m], [n*n] */
     const double *x_goal;      /* QR: [n]; PathQR: [(T+1)*n] */
     const double *u_goal;      /* QR: [m]; PathQR: [T*m] */
@@ -202,6 +210,10 @@ static void model_f(const oracle_model *P, const double *x, const double *u, dou
         return;
     }
     int n = P->n, m = P->m;
+    if (P->model == MODEL_USER) {
+        P->user_f(P->user_p, x, u[0], out);
+        return;
+    }
     if (P->model == MODEL_SIGMOID) {
         for (int i = 0; i < n; ++i) {
             double ax = P->A[i * n + 0] * x[0], z = P->W[i * n + 0] * x[0];
@@ -233,6 +245,10 @@ static void model_fx_fu(const oracle_model *P, const double *x, const double *u,
 {
     if (P->model == MODEL_CARTPOLE) {
         cartpole_fx_fu(P, x, u, fx, fu);
+        return;
+    }
+    if (P->model == MODEL_USER) {
+        P->user_jac(P->user_p, x, u[0], fx, fu);
         return;
     }
     if (P->model == MODEL_SIGMOID) {
@@ -1018,6 +1034,9 @@ typedef struct {
     const double *A, *B, *Q, *R, *Qt, *x_goal, *u_goal, *lower, *upper;
     const double *W;
     double sig_c;
+    user_f_fn user_f;
+    user_jac_fn user_jac;
+    const double *user_p;
 } oracle_model_c;
 
 static oracle_model to_model(const oracle_model_c *c)
@@ -1029,6 +1048,7 @@ static oracle_model to_model(const oracle_model_c *c)
     P.A = c->A; P.B = c->B; P.Q = c->Q; P.R = c->R; P.Qt = c->Qt;
     P.x_goal = c->x_goal; P.u_goal = c->u_goal; P.lower = c->lower; P.upper = c->upper;
     P.W = c->W; P.sig_c = c->sig_c;
+    P.user_f = c->user_f; P.user_jac = c->user_jac; P.user_p = c->user_p;
     return P;
 }
 

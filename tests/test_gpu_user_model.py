@@ -1,0 +1,104 @@
+"""GPU parity of user-defined dynamics (per-model libraries built from tests/models/*.h by
+__graft_entry__.build()).  The reference has no compiled-model mechanism: its counterpart is a
+Python Dynamics object evaluated per step (ilqr/ilqr_dynamics.py:94-575).  Pinning: the cart-pole
+written as a user model must reproduce the built-in cart-pole path, which the reference runs pin;
+the pendulum is compared with the oracle's generic solver on the same model source.  Bar: ==."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as co  # noqa: E402
+from test_user_model_cpu import cartpole_as_user, pendulum, pendulum_batch  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ilqr_amd import _hip
+    _hip.lib()
+    return _hip
+
+
+def dev(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda:0")
+
+
+def eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def compare(out, ref, B):
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+    tr = {key: out["trace"][key].cpu().numpy().T for key in out["trace"]}
+    for b in range(B):
+        it = int(ref["iters"][b])
+        for key in ("J", "accepted", "alpha_idx", "mu", "delta", "qp_iter", "qp_backtrack", "n_clamped", "stopped_at"):
+            assert eq(tr[key][b, :it], ref["trace"][key][b, :it]), (b, key)
+
+
+def test_user_cartpole_equals_builtin_path_and_oracle(hip):
+    from ilqr_amd import user_model as um
+    T, B = 100, 200
+    Mb, Mu = cartpole_as_user(T)
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=21, seed_u=22)
+    ref = co.solve(Mu, co.Opts(max_iter=200), x0, us0, nthreads=8)
+    M = um.UserModel(um.load("cartpole_user"), T, Mu.user_params, Mu.Q, Mu.R, Mu.Qt, Mu.x_goal, None, Mu.lower, Mu.upper)
+    out = um.solve(M, hip.Opts(max_iter=200), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    compare(out, ref, B)
+    Mh = hip.Model(T=T, Q=Mb.Q, R=Mb.R, Q_terminal=Mb.Qt, x_goal=Mb.x_goal, lower=Mb.lower, upper=Mb.upper)
+    blt = hip.solve(Mh, hip.Opts(max_iter=200), dev(x0), dev(us0))
+    for key in ("xs", "us", "J", "iters", "status"):
+        assert eq(out[key].cpu().numpy(), blt[key].cpu().numpy()), key
+    assert (ref["trace"]["n_clamped"] > 0).any()
+
+
+def test_user_pendulum_equals_oracle(hip):
+    from ilqr_amd import user_model as um
+    T, B = 80, 333
+    Mo = pendulum(T)
+    x0, us0 = pendulum_batch(B, T, seed=31)
+    ref = co.solve(Mo, co.Opts(max_iter=60), x0, us0, nthreads=8)
+    M = um.UserModel(um.load("pendulum_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower, Mo.upper)
+    out = um.solve(M, hip.Opts(max_iter=60), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    compare(out, ref, B)
+    assert (ref["trace"]["n_clamped"] > 0).any()
+
+
+def test_user_model_through_the_solver_api(hip):
+    from ilqr_amd import QRCost, iLQR
+    from ilqr_amd.user_model import UserDynamics
+    T, B = 50, 17
+    Mo = pendulum(T)
+    x0, us0 = pendulum_batch(B, T, seed=41)
+    ref = co.solve(Mo, co.Opts(max_iter=30), x0, us0, nthreads=8)
+    dyn = UserDynamics("pendulum_user", Mo.user_params, max_control=2.0)
+    cost = QRCost(Mo.Q, Mo.R, Q_terminal=Mo.Qt, x_goal=Mo.x_goal)
+    s = iLQR(dyn, cost, T)
+    xs, us = s.update_u(x0, us0, n_iterations=30)
+    assert xs.shape == (B, T + 1, 3) and eq(xs, ref["xs"]) and eq(us, ref["us"])
+    assert np.array_equal(s.iterations_, ref["iters"])
+    log = []
+    t = iLQR(dyn, cost, T)
+    xs1, us1 = t.update_u(x0[0], us0[0], n_iterations=30,
+                          on_iteration=lambda it, xs_, us_, J, acc, conv: log.append((it, J, acc, conv)))
+    it_n = int(ref["iters"][0])
+    assert eq(us1, ref["us"][0]) and len(log) == it_n
+
+
+def test_user_model_rejects_mismatched_dimensions(hip):
+    from ilqr_amd import user_model as um
+    lib = um.load("pendulum_user")
+    M = um.UserModel(lib, 10, [0.05, 9.81, 0.2, 1.5], np.eye(3), [[1.0]], None, None, None, [-1.0], [1.0])
+    M.c.n = 4
+    with pytest.raises(hip.IlqrHipError):
+        um.solve(M, hip.Opts(max_iter=2), dev(np.zeros((2, 3))), dev(np.zeros((2, 10, 1))))

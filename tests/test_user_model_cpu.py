@@ -1,0 +1,79 @@
+"""User-defined dynamics, CPU side: the model headers under tests/models compile for the host
+(oracle/user_model_shim.c), and the oracle run on the cart-pole written as a user model is the
+oracle run on its built-in cart-pole, bit for bit (same expressions, same solver code)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from oracle import c_oracle as co
+
+MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+
+
+def cartpole_as_user(T):
+    lib = co.build_user_model(os.path.join(MODELS, "cartpole_user.h"), "cartpole_user")
+    Mb = co.cartpole_model(T=T)
+    Mu = co.user_model(lib, [0.05, 1.0, 0.1, 1.0, 9.8], T, Mb.Q, Mb.R, Mb.Qt, Mb.x_goal, None, Mb.lower, Mb.upper)
+    return Mb, Mu
+
+
+def pendulum(T):
+    lib = co.build_user_model(os.path.join(MODELS, "pendulum_user.h"), "pendulum_user")
+    Q = np.diag([20.0, 20.0, 1.0])
+    return co.user_model(lib, [0.05, 9.81, 0.2, 1.5], T, Q, [[0.5]], 100.0 * np.eye(3), [0.0, 1.0, 0.0], None,
+                         [-2.0], [2.0])
+
+
+def pendulum_batch(B, T, seed=3):
+    r = np.random.RandomState(seed)
+    th, w = r.uniform(-np.pi, np.pi, B), r.uniform(-1, 1, B)
+    return np.stack([np.sin(th), np.cos(th), w], axis=1), r.uniform(-1, 1, (B, T, 1))
+
+
+def test_user_cartpole_is_the_builtin_cartpole():
+    T, B = 40, 12
+    Mb, Mu = cartpole_as_user(T)
+    x0, us0 = co.cartpole_batch(B, T=T)
+    fb, fub = co.dynamics(Mb, x0[0], us0[0, 0]), co.dynamics(Mu, x0[0], us0[0, 0])
+    for a, b in zip(fb, fub):
+        assert np.array_equal(a, b)
+    a = co.solve(Mb, co.Opts(max_iter=30), x0, us0)
+    b = co.solve(Mu, co.Opts(max_iter=30), x0, us0)
+    for key in ("xs", "us", "J", "mu", "delta", "k", "K", "iters", "status"):
+        assert np.array_equal(a[key], b[key]), key
+
+
+def test_pendulum_jacobian_matches_finite_differences_and_solve_descends():
+    T, B = 60, 6
+    M = pendulum(T)
+    x0, us0 = pendulum_batch(B, T)
+    f, fx, fu = co.dynamics(M, x0[0], us0[0, 0])
+    eps = 1e-6
+    for j in range(3):
+        d = np.zeros(3)
+        d[j] = eps
+        fp, fm = co.dynamics(M, x0[0] + d, us0[0, 0])[0], co.dynamics(M, x0[0] - d, us0[0, 0])[0]
+        np.testing.assert_allclose(fx[0][:, j], (fp[0] - fm[0]) / (2 * eps), atol=1e-7)
+    fp, fm = co.dynamics(M, x0[0], us0[0, 0] + eps)[0], co.dynamics(M, x0[0], us0[0, 0] - eps)[0]
+    np.testing.assert_allclose(fu[0][:, 0], (fp[0] - fm[0]) / (2 * eps), atol=1e-7)
+    J0 = co.rollout_cost(M, x0, us0)[1]
+    out = co.solve(M, co.Opts(max_iter=40), x0, us0)
+    # (the reference's forward pass does not clip u + alpha k + K dx, so |u| may exceed the bound)
+    assert (out["J"] < J0).all() and (out["trace"]["n_clamped"] > 0).any()
+
+
+def test_user_model_libraries_export_every_declared_symbol():
+    import re
+    from ilqr_amd import user_model as um
+    root = os.path.dirname(MODELS.rstrip("/").rsplit("/", 1)[0])
+    header = open(os.path.join(root, "include", "ilqr_user.h")).read()
+    body = header[header.index("#ifndef ILQR_USER_H"):]
+    declared = set(re.findall(r"\b(ilqr_user_[a-z0-9_]+)\s*\(", body))
+    assert declared == {"ilqr_user_dims", "ilqr_user_workspace_bytes", "ilqr_user_solve_batched"}
+    for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4))):
+        lib = C.CDLL(um.library_path(name))  # loading needs no GPU
+        for sym in declared:
+            assert hasattr(lib, sym), (name, sym)
+        n, npar = C.c_int32(), C.c_int32()
+        assert lib.ilqr_user_dims(C.byref(n), C.byref(npar)) == 0 and (n.value, npar.value) == dims
