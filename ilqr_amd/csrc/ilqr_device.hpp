@@ -530,6 +530,18 @@ __device__ __forceinline__ bool qp_spin_proved(const QPOptsP& O, double H, doubl
     return den_pos & (hD + Ep < 0.0) & (Ep < O.armijo * 1e-10);
 }
 
+#ifdef ILQR_QP_PROF // diagnostic build only: per-wave event counts of boxqp1
+static __device__ unsigned long long g_qp_prof[16];
+__device__ __forceinline__ void qp_count(int slot)
+{
+    if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1)
+        atomicAdd(&g_qp_prof[slot], 1ull);
+}
+#define QP_COUNT(slot) qp_count(slot)
+#else
+#define QP_COUNT(slot)
+#endif
+
 struct QP1Out {
     double x;      // solution
     double rdiag;  // reciprocal of the 1x1 free-subspace Cholesky factor (1.0: never factorised, H_ff = ones)
@@ -545,8 +557,10 @@ struct QP1Out {
 // sqrtH, rsqrtH: sqrt(H) and 1.0 / sqrt(H) as the caller already has them from
 // its own Cholesky of the same 1x1 matrix (same input, same bits).
 // tab: the workgroup's step table (qp_fill_step_table).
-__device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, double H, double sqrtH, double rsqrtH,
-                                       double g, double lo, double hi, double x0, QP1Out& out)
+// This is the literal loop, any number of passes; boxqp1() below tries the common
+// three-pass shape as straight-line code first.
+__device__ __forceinline__ void boxqp1_loop(const QPOptsP& O, const double* tab, double H, double sqrtH, double rsqrtH,
+                                            double g, double lo, double hi, double x0, QP1Out& out)
 {
     bool clamped = false, free_ = false;
     double oldvalue = 0.0;
@@ -564,9 +578,13 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
     // of the wave is active.
     bool active = true;
     double grad = 0.0;
+    QP_COUNT(0);
+    int passes = 0;
     for (int iter = 0; iter < O.max_iter; ++iter) {
         if (__ballot(active) == 0ull)
             break;
+        QP_COUNT(1);
+        ++passes;
         bool ex4 = active & (iter > 1) & ((oldvalue - value) < O.min_rel * fabs(oldvalue)) & ((oldvalue - value) > 0.0);
         result = ex4 ? 4 : result;
         active = active & !ex4;
@@ -589,6 +607,7 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
         n_iter += active ? 1 : 0;
         if (__ballot(active) == 0ull) // typical last pass: every lane has just left
             break;
+        QP_COUNT(2);
         double rhs = g + 0.0;
         double sol = (rhs * rdiag) * rdiag;
         double search = sol * -1 - x;
@@ -606,6 +625,9 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
         double vc = qp_value1(H, g, xc);
         bool more = active & quotient_below(vc - oldvalue, sdotg + 1e-10, O.armijo);
         if (__ballot(more) != 0ull) {
+            QP_COUNT(3);
+            if (iter >= 1)
+                QP_COUNT(6);
             double ax = fabs(x), G = fabs(grad), as = fabs(search);
             double gerr = 5e-16 * (fabs(g) + fabs(H * x)); // |computed grad - exact g + H x| stays below this
             bool descent = (((search > 0.0) & (grad < 0.0)) | ((search < 0.0) & (grad > 0.0))) & (G > 4.0 * gerr);
@@ -637,6 +659,7 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
             nstep = exhaust ? O.n_exhaust : (jump ? tj : nstep);
             result = exhaust ? 2 : result;
             if (__ballot(exhaust | jump) != 0ull) {
+                QP_COUNT(4);
                 double xn = clamp1(lo, hi, x + step * search);
                 xc = (exhaust | jump) ? xn : xc;
                 vc = qp_value1(H, g, xc);
@@ -646,6 +669,7 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
             }
             int trip = 0; // same for every lane still in the loop
             while (more) {
+                QP_COUNT(5);
                 bool ex = (xc == x);
                 if ((trip & 3) == 3) {
                     double D = 1.001 * (step * as) + 4e-16 * ax;
@@ -667,6 +691,7 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
         value = active ? vc : value;
         active = active & (result == -1);
     }
+    (void)passes;
     out.x = x;
     out.rdiag = rdiag;
     out.hff = hff;
@@ -675,6 +700,184 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
     out.n_iter = n_iter;
     out.n_factor = n_factor;
     out.n_backtrack = n_bt;
+}
+
+// ---- the common shape of boxqp1_loop as (almost) straight-line code ------------
+//
+// Almost every call makes exactly three passes: pass 0 (H_ff = ones) backtracks to some
+// trip t_j and accepts, pass 1 (factorised) accepts the full Newton step or exhausts the
+// search near convergence, pass 2 ends on one of the termination tests.  boxqp1() runs
+// that shape for all lanes at once: no per-pass predication (a lane that has left simply
+// computes values nobody reads; the outputs are selected at the end from the stage at
+// which the lane left), one evaluated candidate per pass (pass 0: at tab[t_j] when the
+// jump proof shows that every earlier trip continues, which covers the candidate at
+// step 1 as well), and the exhaustion proof behind a wave-uniform branch that is taken
+// only when some lane's candidate was rejected.  Same operations on the same operands as
+// the loop, hence the same bits and counters.  A lane whose call has any other shape (a
+// rejected candidate without proof, a fourth pass, a NaN, an undecided quotient) reports
+// `slow`, and the wave then runs the literal loop from the start.
+
+// fmax(lo, fmin(hi, v)); NaN operands are left to the literal loop.
+__device__ __forceinline__ double qp_clamp_fast(double lo, double hi, double v, bool& slow)
+{
+    slow = slow | (v != v);
+    return fmax(lo, fmin(hi, v));
+}
+
+// quotient_below without the division: undecided cases are left to the literal loop.
+__device__ __forceinline__ bool qp_quotient_fast(double num, double den, double a, bool& slow)
+{
+    double p = a * den;
+    double tol = fabs(p) * 1e-12;
+    bool lo = num < p - tol, hi = num > p + tol;
+    bool pos = den > 0.0, neg = den < 0.0;
+    bool sure_true = (pos & lo) | (neg & hi);
+    bool sure_false = (pos & hi) | (neg & lo);
+    slow = slow | !(sure_true | sure_false);
+    return sure_true;
+}
+
+// One candidate of the line search (ilqr_boxQP.py:141-151): true if the search goes on.
+__device__ __forceinline__ bool qp_candidate(const QPOptsP& O, double H, double g, double lo, double hi, double x,
+                                             double search, double grad, double oldvalue, double step, bool& slow,
+                                             double& xc, double& vc)
+{
+    xc = qp_clamp_fast(lo, hi, x + step * search, slow);
+    vc = qp_value1(H, g, xc);
+    double sdotg = (xc - x) * grad;
+    return qp_quotient_fast(vc - oldvalue, sdotg + 1e-10, O.armijo, slow);
+}
+
+// Does the search from x along `search` provably exhaust (see boxqp1_loop)?  Also returns the
+// candidate the exhausted loop ends on.  The proof covers every candidate, the first included.
+__device__ __forceinline__ bool qp_exhausts(const QPOptsP& O, double H, double g, double lo, double hi, double x,
+                                            double search, double grad, bool& slow, double& xl, double& vl)
+{
+    double xc1 = qp_clamp_fast(lo, hi, x + search, slow); // step 1.0: step * search == search
+    double ax = fabs(x), G = fabs(grad), as = fabs(search);
+    double gerr = 5e-16 * (fabs(g) + fabs(H * x));
+    bool descent = (((search > 0.0) & (grad < 0.0)) | ((search < 0.0) & (grad > 0.0))) & (G > 4.0 * gerr);
+    double D0 = 1.001 * as + 4e-16 * ax;
+    double Ep = qp_error_budget(O, H, g, ax, G, gerr, D0);
+    slow = slow | !(G < __builtin_inf()); // a non-finite gradient defeats "xc == x implies rejected"
+    xl = qp_clamp_fast(lo, hi, x + O.step_last * search, slow);
+    vl = qp_value1(H, g, xl);
+    return (xc1 == x) | qp_spin_proved(O, H, G, gerr, descent, D0, Ep);
+}
+
+__device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, double H, double sqrtH, double rsqrtH,
+                                       double g, double lo, double hi, double x0, QP1Out& out)
+{
+    const bool opts_ok = (O.max_iter >= 3) & (O.armijo > 0.0) & (O.armijo < 1.0); // wave-uniform
+    if (!opts_ok) {
+        boxqp1_loop(O, tab, H, sqrtH, rsqrtH, g, lo, hi, x0, out);
+        return;
+    }
+    bool slow = (lo != lo) | (hi != hi) | !(H > 0.0), s;
+    const double xa = qp_clamp_fast(lo, hi, x0, slow);
+    const double va = qp_value1(H, g, xa);
+    const double rhs = g + 0.0;
+
+    // ---- pass 0 (:87-137 with H_ff = ones, then the line search)
+    const double grad0 = g + H * xa;
+    const bool cl0 = ((xa == lo) & (grad0 > 0.0)) | ((xa == hi) & (grad0 < 0.0));
+    const bool e05 = !cl0 & (fabs(grad0) < O.min_grad);
+    const bool act0 = !(cl0 | e05);
+    const double search0 = rhs * -1 - xa; // (rhs * 1.0) * 1.0 == rhs
+    bool jump;
+    int tj;
+    double sj;
+    {   // jump proof (see boxqp1_loop): every trip before tj continues
+        double ax = fabs(xa), G = fabs(grad0), as = fabs(search0);
+        double gerr = 5e-16 * (fabs(g) + fabs(H * xa));
+        bool descent = (((search0 > 0.0) & (grad0 < 0.0)) | ((search0 < 0.0) & (grad0 > 0.0))) & (G > 4.0 * gerr);
+        double D0 = 1.001 * as + 4e-16 * ax;
+        double Ep = qp_error_budget(O, H, g, ax, G, gerr, D0);
+        float Gf = (float)G, Hf = (float)H, cf = (float)(1.0 - O.armijo);
+        float cg = cf * Gf;
+        float up = (cg + __builtin_amdgcn_sqrtf(cg * cg + (float)(2e-10 * O.armijo) * Hf)) * __builtin_amdgcn_rcpf(Hf);
+        float U = fmaxf(up, 1e-10f * __builtin_amdgcn_rcpf(Gf));
+        float tf = __builtin_amdgcn_logf(U * __builtin_amdgcn_rcpf((float)as)) * O.inv_log2_dec;
+        tf = fminf(fmaxf(tf, 0.0f), 1.0e6f); // NaN -> 0
+        tj = (int)tf + 1;
+        tj = tj < O.tab_n ? tj : O.tab_n - 1;
+        bool try_jump = descent & (tj >= 2);
+        tj = try_jump ? tj : 1;
+        double sv = tab[tj - 1];
+        sj = tab[tj];
+        s = false;
+        double xv = qp_clamp_fast(lo, hi, xa + sv * search0, s);
+        double dv = xv - xa, uv = fabs(dv);
+        double hv = (0.5 * H * uv) * uv - ((1.0 - O.armijo) * (G + gerr)) * uv - O.armijo * 1e-10;
+        jump = try_jump & (hv > Ep) & (fabs(dv * grad0) > 1.0000001e-10) & !s;
+    }
+    int n0 = jump ? tj : 0;
+    double xb, vb;
+    s = false;
+    const bool rej0 = qp_candidate(O, H, g, lo, hi, xa, search0, grad0, va, jump ? sj : 1.0, s, xb, vb);
+    slow = slow | (act0 & s);
+    bool exh0 = false;
+    if (__ballot(act0 & rej0) != 0ull) {
+        double xl, vl;
+        s = false;
+        bool ex = qp_exhausts(O, H, g, lo, hi, xa, search0, grad0, s, xl, vl);
+        exh0 = act0 & rej0 & ex;
+        slow = slow | (act0 & rej0 & (s | !ex)); // rejected without proof: more trips
+        xb = exh0 ? xl : xb;
+        vb = exh0 ? vl : vb;
+        n0 = exh0 ? O.n_exhaust : n0;
+    }
+
+    // ---- pass 1: factorised Newton step
+    const bool act1 = act0 & !exh0;
+    const double grad1 = g + H * xb;
+    const bool cl1 = ((xb == lo) & (grad1 > 0.0)) | ((xb == hi) & (grad1 < 0.0));
+    const bool e16 = act1 & cl1;
+    const bool fz = act1 & !cl1; // factorised (:108-117 precede the gradient test)
+    const bool e15 = fz & (fabs(grad1) < O.min_grad);
+    const bool act1b = fz & !e15;
+    const double search1 = ((rhs * rsqrtH) * rsqrtH) * -1 - xb;
+    double xc, vc;
+    s = false;
+    const bool rej1 = qp_candidate(O, H, g, lo, hi, xb, search1, grad1, vb, 1.0, s, xc, vc);
+    slow = slow | (act1b & s);
+    bool exh1 = false;
+    if (__ballot(act1b & rej1) != 0ull) {
+        double xl, vl;
+        s = false;
+        bool ex = qp_exhausts(O, H, g, lo, hi, xb, search1, grad1, s, xl, vl);
+        exh1 = act1b & rej1 & ex;
+        slow = slow | (act1b & rej1 & (s | !ex));
+        xc = exh1 ? xl : xc;
+        vc = exh1 ? vl : vc;
+    }
+
+    // ---- pass 2: termination tests only (:87-137)
+    const bool act2 = act1b & !exh1;
+    const double dv2 = vb - vc;
+    const bool e24 = act2 & (dv2 < O.min_rel * fabs(vb)) & (dv2 > 0.0);
+    const double grad2 = g + H * xc;
+    const bool cl2 = ((xc == lo) & (grad2 > 0.0)) | ((xc == hi) & (grad2 < 0.0));
+    const bool rest2 = act2 & !e24;
+    const bool e26 = rest2 & cl2;
+    const bool e25 = rest2 & !cl2 & (fabs(grad2) < O.min_grad);
+    slow = slow | (rest2 & !cl2 & !e25); // a third line search
+    QP_COUNT(9);
+    if (__ballot(slow) != 0ull) {
+        QP_COUNT(7);
+        boxqp1_loop(O, tab, H, sqrtH, rsqrtH, g, lo, hi, x0, out);
+        return;
+    }
+    // outputs, by the stage at which the lane left
+    const bool left0 = !act0, left1 = !left0 & (exh0 | e16 | e15); // everything else left in or after pass 1's search
+    out.x = left0 ? xa : (left1 ? xb : xc);
+    out.rdiag = fz ? rsqrtH : 1.0;
+    out.hff = fz ? sqrtH : 1.0;
+    out.result = (cl0 | e16 | e26) ? 6 : ((e05 | e15 | e25) ? 5 : ((exh0 | exh1) ? 2 : 4));
+    out.free_ = !(cl0 | e16 | e26);
+    out.n_iter = (act0 ? 1 : 0) + (act1b ? 1 : 0);
+    out.n_factor = fz ? 1 : 0;
+    out.n_backtrack = (act0 ? n0 : 0) + (exh1 ? O.n_exhaust : 0);
 }
 
 // ---- backward step ----------------------------------------------------------
@@ -813,7 +1016,16 @@ __device__ __forceinline__ int bw_finish(const QPOptsP& QO, const double* tab, c
 
     // boxQP(Q_uu, Q_u, lower - u, upper - u, k[i], ...)     (:152-156)
     QP1Out qp;
+#ifdef ILQR_ABLATE_QP // timing diagnostic only (wrong numerics): the clamped Newton point instead of boxQP
+    qp.x = clamp1(lower - u, upper - u, k0 * -1);
+    qp.rdiag = rL;
+    qp.hff = L;
+    qp.result = 5;
+    qp.free_ = (qp.x > lower - u) & (qp.x < upper - u);
+    qp.n_iter = qp.n_factor = qp.n_backtrack = 0;
+#else
     boxqp1(QO, tab, Quu, L, rL, Qu, lower - u, upper - u, k0, qp);
+#endif
     double kk = qp.x;
     S.qp_iter += qp.n_iter;
     S.qp_backtrack += qp.n_backtrack;

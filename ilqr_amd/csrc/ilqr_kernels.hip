@@ -272,7 +272,15 @@ __device__ __forceinline__ int backward_sweep(const CartpoleC& P, const Cost& C,
                 det_sincos(th + x[4] * P.dt, sn, cn);
             }
             CartpoleJac J;
+#ifdef ILQR_ABLATE_JAC // timing diagnostic only (wrong numerics): a Jacobian that costs nothing
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 3; ++c)
+                    J.a[r][c] = x[r + 1] + sn;
+            J.b1 = x[0];
+            J.b4 = cn;
+#else
             cartpole_jac(P, x, u, sn, cn, J);
+#endif
             C.at(i);
             double kt, Kt[NX];
             int qr;
@@ -1501,6 +1509,16 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
                            B, (int)m, H, g, lower, upper, x0, x, result, Hff, hff_dim, free_mask, counters);
     return hip_status(hipGetLastError());
 }
+
+#ifdef ILQR_QP_PROF
+int ilqr_debug_qp_prof(unsigned long long* host16, int reset)
+{
+    unsigned long long z[16] = {0};
+    if (reset)
+        return hip_status(hipMemcpyToSymbol(HIP_SYMBOL(ilqr::g_qp_prof), z, sizeof(z)));
+    return hip_status(hipMemcpyFromSymbol(host16, HIP_SYMBOL(ilqr::g_qp_prof), sizeof(z)));
+}
+#endif
 
 int ilqr_debug_wave_log(void* device_buffer)
 {

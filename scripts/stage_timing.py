@@ -7,6 +7,8 @@ from ilqr_amd import _hip
 import bench
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+if len(sys.argv) > 2:  # a differently compiled build of the library (diagnostics)
+    _hip.LIB_PATH = os.path.abspath(sys.argv[2])
 T = 100
 dev = torch.device("cuda:0")
 Q, R, Qt, xg = bench.cartpole_cost()
