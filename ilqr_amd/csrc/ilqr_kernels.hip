@@ -446,32 +446,38 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost
                                                   double* __restrict__ xs_new,
                                                   double* __restrict__ us_new)
 {
-    double xn[NX], xo[NX], Kr[NX], xt[NX];
+    // The operands of a step (old x, u, k, K: 12 numbers) are loaded TWO steps ahead: with one
+    // wave per SIMD the bytes in flight are what sets the achieved bandwidth of a large batch.
+    struct Ops {
+        double xo[NX], Kr[NX], u, kk;
+    };
+    auto fetch = [&](int t, Ops& o) {
+        load5(xs, ld, (int64_t)t * NX, b, o.xo);
+        load5(K, ld, (int64_t)t * NX, b, o.Kr);
+        o.u = us[(int64_t)t * ld + b];
+        o.kk = k[(int64_t)t * ld + b];
+    };
+    double xn[NX], xt[NX];
     load5(xs, ld, 0, b, xn);
     double J = 0.0;
-    // operands of step 0
-    load5(xs, ld, 0, b, xo);
-    load5(K, ld, 0, b, Kr);
-    double u = us[b], kk = k[b];
+    Ops cur, nxt;
+    fetch(0, cur);
+    fetch(T > 1 ? 1 : 0, nxt);
     // (x_t, u_t) of the previous step, stored one step late (see keep_alive)
     double pend_x[NX], pend_u = 0.0;
 #pragma unroll
     for (int a = 0; a < NX; ++a)
         pend_x[a] = xn[a];
+#pragma unroll 2
     for (int t = 0; t < T; ++t) {
-        // prefetch step t+1 (the last step re-reads itself)
-        double xo_p[NX], Kr_p[NX], u_p, kk_p;
-        int tp = t + 1 < T ? t + 1 : t;
-        load5(xs, ld, (int64_t)tp * NX, b, xo_p);
-        load5(K, ld, (int64_t)tp * NX, b, Kr_p);
-        u_p = us[(int64_t)tp * ld + b];
-        kk_p = k[(int64_t)tp * ld + b];
+        Ops far; // step t+2 (the last steps re-read the last one)
+        fetch(t + 2 < T ? t + 2 : T - 1, far);
         if (STORE) { // step t-1 (at t = 0: x_0 and a placeholder u_0, rewritten at t = 1)
             int ts = t > 0 ? t - 1 : 0;
             store5(xs_new, ld, (int64_t)ts * NX, b, pend_x);
             us_new[(int64_t)ts * ld + b] = pend_u;
         }
-        double un = fw_control(xn, xo, u, kk, Kr, alpha);
+        double un = fw_control(xn, cur.xo, cur.u, cur.kk, cur.Kr, alpha);
         C.at(t);
         J = J + C.l(xn, un);
         cartpole_f(P, xn, un, xt);
@@ -486,11 +492,9 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost
         for (int a = 0; a < NX; ++a) {
             pend_x[a] = xn[a];
             xn[a] = xt[a];
-            xo[a] = xo_p[a];
-            Kr[a] = Kr_p[a];
         }
-        u = u_p;
-        kk = kk_p;
+        cur = nxt;
+        nxt = far;
     }
     if (STORE) {
         store5(xs_new, ld, (int64_t)(T - 1) * NX, b, pend_x);

@@ -35,3 +35,17 @@ print("distinct SIMDs used by waves started in the first ms:", len(np.unique(key
 print("distinct CUs:", len(np.unique(key[first] // 10)))
 iters = res["iters"].cpu().numpy().reshape(nw, -1).max(axis=1)
 print("per-wave max iterations: min %d mean %.1f" % (iters.min(), iters.mean()))
+# wave lifetime by how many waves share the wave's CU / SIMD
+cukey = key // 10
+life = end - start
+for name, k_ in (("CU", cukey), ("SIMD", key)):
+    uniq, inv, cnt = np.unique(k_, return_inverse=True, return_counts=True)
+    share = cnt[inv]
+    print("waves per %s -> count of waves, mean / max life (ms):" % name)
+    for s_ in np.unique(share):
+        m = share == s_
+        print("   %2d: %5d waves  %.1f / %.1f" % (s_, int(m.sum()), life[m].mean(), life[m].max()))
+xcc = L[:, 3]
+print("waves per XCC:", np.bincount(xcc.astype(int)))
+q = np.percentile(life, [5, 25, 50, 75, 95, 100])
+print("life percentiles 5/25/50/75/95/100: " + " ".join("%.1f" % v for v in q))
