@@ -34,6 +34,7 @@
 #error "compile with -DILQR_USER_MODEL='\"path/to/model.h\"'"
 #endif
 #include ILQR_USER_MODEL
+#include "../../include/ilqr_user_fd.h" // ilqr_user_jac by forward differences if the model asks for it
 
 namespace {
 

@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _TU = os.path.join(_HERE, "csrc", "ilqr_user_tu.hip")
 _DEPS = [_TU, os.path.join(_HERE, "csrc", "ilqr_device.hpp"), os.path.join(_HERE, "csrc", "ilqr_math.hpp"),
          os.path.join(os.path.dirname(_HERE), "include", "ilqr_user.h"),
+         os.path.join(os.path.dirname(_HERE), "include", "ilqr_user_fd.h"),
          os.path.join(os.path.dirname(_HERE), "include", "ilqr_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

@@ -10,6 +10,8 @@
  *     ILQR_FN void ilqr_user_jac(const double* p, const double* x, double u,
  *                                double* fx, double* fu);   (fx: [N][N] row-major, fu: [N])
  *
+ * (or, instead of ilqr_user_jac,  #define ILQR_USER_FD : forward-difference Jacobian as the
+ * reference's FiniteDifferenceDynamics, see ilqr_user_fd.h)
  * that may use ilqr_sincos(x, &s, &c), ilqr_atan2(y, x), ilqr_sqrt(x) and plain arithmetic;
  * ilqr_amd/csrc/ilqr_user_tu.hip is compiled around it into one shared library per model
  * (ilqr_amd.user_model.build_user_model does that with hipcc).  That library exports the

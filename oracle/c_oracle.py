@@ -346,7 +346,7 @@ def build_user_model(header, name):
     header = os.path.abspath(header)
     out = os.path.join(_HERE, "libusermodel_%s.so" % name)
     shim = os.path.join(_HERE, "user_model_shim.c")
-    if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in (header, shim))):
+    if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in (header, shim, os.path.join(_HERE, "..", "include", "ilqr_user_fd.h")))):
         subprocess.run(["gcc", "-O2", "-mfma", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-shared",
                         "-DILQR_USER_MODEL=\"%s\"" % header, "-I", _HERE, shim, "-o", out, "-lm"], check=True)
     return C.CDLL(out)

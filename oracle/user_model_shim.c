@@ -10,6 +10,7 @@
 #define ilqr_atan2(y, x) dm_atan2((y), (x))
 #define ilqr_sqrt(x) sqrt(x)
 #include ILQR_USER_MODEL
+#include "../include/ilqr_user_fd.h"
 
 int user_model_n(void) { return ILQR_USER_N; }
 int user_model_np(void) { return ILQR_USER_NP; }

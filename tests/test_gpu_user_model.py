@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from oracle import c_oracle as co  # noqa: E402
-from test_user_model_cpu import cartpole_as_user, pendulum, pendulum_batch  # noqa: E402
+from test_user_model_cpu import cartpole_as_user, pendulum, pendulum_batch, pendulum_fd  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -72,6 +72,21 @@ def test_user_pendulum_equals_oracle(hip):
     torch.cuda.synchronize()
     compare(out, ref, B)
     assert (ref["trace"]["n_clamped"] > 0).any()
+
+
+def test_forward_difference_user_model_equals_oracle(hip):
+    """A model with no analytic Jacobian (forward differences, FiniteDifferenceDynamics' rule):
+    the same f evaluations and the same divisions on both sides, so == holds here too."""
+    from ilqr_amd import user_model as um
+    T, B = 60, 150
+    Mo = pendulum_fd(T)
+    x0, us0 = pendulum_batch(B, T, seed=51)
+    ref = co.solve(Mo, co.Opts(max_iter=40), x0, us0, nthreads=8)
+    M = um.UserModel(um.load("pendulum_fd_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower,
+                     Mo.upper)
+    out = um.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    compare(out, ref, B)
 
 
 def test_user_model_through_the_solver_api(hip):

@@ -25,6 +25,13 @@ def pendulum(T):
                          [-2.0], [2.0])
 
 
+def pendulum_fd(T):
+    """The same pendulum with forward-difference derivatives (FiniteDifferenceDynamics' rule)."""
+    lib = co.build_user_model(os.path.join(MODELS, "pendulum_fd_user.h"), "pendulum_fd_user")
+    Ma = pendulum(T)
+    return co.user_model(lib, Ma.user_params, T, Ma.Q, Ma.R, Ma.Qt, Ma.x_goal, None, Ma.lower, Ma.upper)
+
+
 def pendulum_batch(B, T, seed=3):
     r = np.random.RandomState(seed)
     th, w = r.uniform(-np.pi, np.pi, B), r.uniform(-1, 1, B)
@@ -63,6 +70,32 @@ def test_pendulum_jacobian_matches_finite_differences_and_solve_descends():
     assert (out["J"] < J0).all() and (out["trace"]["n_clamped"] > 0).any()
 
 
+def test_forward_difference_model_follows_approx_fprime():
+    """ilqr/ilqr_dynamics.py:145-167: row m of f_x is approx_fprime(x, f(.)[m], x_eps), i.e.
+    (f(x + eps e_k) - f(x)) / eps with eps = sqrt(machine epsilon); checked against that formula
+    evaluated with the oracle's own f, and against the analytic Jacobian."""
+    T = 20
+    Ma, Mf = pendulum(T), pendulum_fd(T)
+    x0, us0 = pendulum_batch(5, T, seed=9)
+    eps = np.sqrt(np.finfo(float).eps)
+    for b in range(5):
+        x, u = x0[b], us0[b, 0]
+        f, fx, fu = co.dynamics(Mf, x, u)
+        fa, fxa, fua = co.dynamics(Ma, x, u)
+        assert np.array_equal(f, fa)
+        for k in range(3):
+            d = np.zeros(3)
+            d[k] = eps
+            col = (co.dynamics(Ma, x + d, u)[0][0] - fa[0]) / eps
+            assert np.array_equal(fx[0][:, k], col)
+        assert np.array_equal(fu[0][:, 0], (co.dynamics(Ma, x, u + eps)[0][0] - fa[0]) / eps)
+        np.testing.assert_allclose(fx[0], fxa[0], atol=2e-7)
+        np.testing.assert_allclose(fu[0], fua[0], atol=2e-7)
+    a = co.solve(Ma, co.Opts(max_iter=30), x0, us0)
+    b_ = co.solve(Mf, co.Opts(max_iter=30), x0, us0)
+    np.testing.assert_allclose(b_["J"], a["J"], rtol=1e-3)
+
+
 def test_user_model_libraries_export_every_declared_symbol():
     import re
     from ilqr_amd import user_model as um
@@ -71,7 +104,7 @@ def test_user_model_libraries_export_every_declared_symbol():
     body = header[header.index("#ifndef ILQR_USER_H"):]
     declared = set(re.findall(r"\b(ilqr_user_[a-z0-9_]+)\s*\(", body))
     assert declared == {"ilqr_user_dims", "ilqr_user_workspace_bytes", "ilqr_user_solve_batched"}
-    for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4))):
+    for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4)), ("pendulum_fd_user", (3, 4))):
         lib = C.CDLL(um.library_path(name))  # loading needs no GPU
         for sym in declared:
             assert hasattr(lib, sym), (name, sym)
