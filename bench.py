@@ -73,7 +73,7 @@ def main_large(args):
     import torch
     import torch.distributed as dist
     from ilqr_amd import _hip, sharding
-    from oracle import c_oracle as co
+    from ilqr_amd.synthetic import SyntheticWorkload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,10 +86,9 @@ def main_large(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     B, TL, n, m = (args.batch if args.batch != B_PER_GPU else 8192), 200, 32, 8
-    Mo = co.synthetic_model(T=TL)  # the oracle module only supplies the workload definition here
-    M = _hip.LargeModel(TL, Mo.A, Mo.B, Mo.W, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=Mo.dt,
-                        sig_c=Mo.sig_c, device=dev)
-    x0_h, us_h = co.synthetic_batch(B, T=TL, seed_x=5 + 1000 * rank, seed_u=6 + 1000 * rank)
+    wl = SyntheticWorkload(n=n, m=m, T=TL)
+    M = wl.device_model(device=dev)
+    x0_h, us_h = wl.batch(B, seed_x=5 + 1000 * rank, seed_u=6 + 1000 * rank)
     x0, us0 = torch.tensor(x0_h, device=dev), torch.tensor(us_h, device=dev)
     O = _hip.Opts()
     ws = None
@@ -152,6 +151,8 @@ def main_large(args):
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(16, os.cpu_count() or 1))
             n_cpu = 128
+            from oracle import c_oracle as co  # the CPU baseline leg: the checker timed as a C port
+            Mo = co.synthetic_model(T=TL)
             t1 = time.perf_counter()
             co.solve(Mo, co.Opts(), x0_h[:n_cpu], us_h[:n_cpu], nthreads=threads, trace=False)
             dt = time.perf_counter() - t1

@@ -51,3 +51,31 @@ class SigmoidLinearDynamics(Dynamics):
 
     def f_u(self, x, u, i):
         return self.tau * self.B
+
+
+class SyntheticWorkload(object):
+    """The large-state benchmark workload (the reference ships no model of this size): a stable
+    random A, random B and W (``RandomState(seed)``), QRCost towards the origin (Q = I, R = 0.1 I,
+    Q_terminal = 10 I), box limits |u| <= u_max."""
+
+    def __init__(self, n=32, m=8, T=200, seed=4, dt=0.05, sig_c=2.0, u_max=1.0):
+        r = np.random.RandomState(seed)
+        G = r.randn(n, n)
+        self.n, self.m, self.T, self.dt, self.sig_c = n, m, T, dt, sig_c
+        self.A = 0.8 * G / np.abs(np.linalg.eigvals(G)).max() - np.eye(n)
+        self.B = r.randn(n, m) / np.sqrt(m)
+        self.W = r.randn(n, n) / np.sqrt(n)
+        self.Q, self.R, self.Qt = np.eye(n), 0.1 * np.eye(m), 10.0 * np.eye(n)
+        self.x_goal, self.u_goal = np.zeros(n), np.zeros(m)
+        self.lower, self.upper = np.full(m, -u_max), np.full(m, u_max)
+
+    def device_model(self, device=None):
+        from . import _hip
+        return _hip.LargeModel(self.T, self.A, self.B, self.W, self.Q, self.R, self.Qt, self.x_goal, self.u_goal,
+                               self.lower, self.upper, dt=self.dt, sig_c=self.sig_c, device=device)
+
+    def batch(self, B, seed_x=5, seed_u=6):
+        """Initial states ~ U(-1, 1), initial controls ~ U(-0.5, 0.5)."""
+        x0 = np.random.RandomState(seed_x).uniform(-1.0, 1.0, (B, self.n))
+        us = np.random.RandomState(seed_u).uniform(-0.5, 0.5, (B, self.T, self.m))
+        return x0, us

@@ -13,12 +13,12 @@ def child(B, path):
     sys.path.insert(0, ROOT)
     from ilqr_amd import _hip
     _hip.LIB_PATH = os.path.abspath(path)
-    from oracle import c_oracle as co  # inputs only
-    Mb = co.cartpole_model(T=100)
-    x0, us0 = co.cartpole_batch(B, T=100)
+    import bench
+    x0, us0 = bench.make_batch(B, 0)
+    Q, R, Qt, xg = bench.cartpole_cost()
     dx, du = torch.tensor(x0, device="cuda:0"), torch.tensor(us0, device="cuda:0")
     O = _hip.Opts(max_iter=200)
-    M = _hip.Model(T=100, Q=Mb.Q, R=Mb.R, Q_terminal=Mb.Qt, x_goal=Mb.x_goal, lower=Mb.lower, upper=Mb.upper)
+    M = _hip.Model(100, Q, R, Qt, xg, None, [-5.0], [5.0])
     r = _hip.solve(M, O, dx, du)
     torch.cuda.synchronize()
     ts = []

@@ -21,14 +21,13 @@ MFMA_BW_STEP, MFMA_FW_STEP = 208, 76
 def main():
     import torch
     from ilqr_amd import _hip
-    from oracle import c_oracle as co
+    from ilqr_amd.synthetic import SyntheticWorkload
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     dev = torch.device("cuda:0")
-    Mo = co.synthetic_model(T=T)
-    M = _hip.LargeModel(T, Mo.A, Mo.B, Mo.W, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=Mo.dt,
-                        sig_c=Mo.sig_c)
-    x0_h, us_h = co.synthetic_batch(B, T=T)
+    wl = SyntheticWorkload(T=T)
+    M = wl.device_model()
+    x0_h, us_h = wl.batch(B)
     x0, us = torch.tensor(x0_h, device=dev), torch.tensor(us_h, device=dev)
     O = _hip.Opts()
 

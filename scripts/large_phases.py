@@ -9,15 +9,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from ilqr_amd import _hip  # noqa: E402
-from oracle import c_oracle as co  # noqa: E402
+from ilqr_amd.synthetic import SyntheticWorkload  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 T = 200
 dev = torch.device("cuda:0")
-Mo = co.synthetic_model(T=T)
-M = _hip.LargeModel(T, Mo.A, Mo.B, Mo.W, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=Mo.dt,
-                    sig_c=Mo.sig_c)
-x0, us = co.synthetic_batch(B, T=T)
+wl = SyntheticWorkload(T=T)
+M = wl.device_model()
+x0, us = wl.batch(B)
 x0, us = torch.tensor(x0, device=dev), torch.tensor(us, device=dev)
 xs, _ = _hip.large_rollout_cost(M, x0, us)
 mu = torch.ones(B, dtype=torch.float64, device=dev)

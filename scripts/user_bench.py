@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from ilqr_amd import _hip, user_model as um  # noqa: E402
-from oracle import c_oracle as co  # noqa: E402  (inputs only)
+import bench  # noqa: E402
 
 
 def timed(fn, reps=3):
@@ -28,13 +28,12 @@ def timed(fn, reps=3):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     T = 100
-    Mb = co.cartpole_model(T=T)
-    x0, us0 = co.cartpole_batch(B, T=T)
+    x0, us0 = bench.make_batch(B, 0)
+    Q, R, Qt, xg = bench.cartpole_cost()
     dx, du = torch.tensor(x0, device="cuda:0"), torch.tensor(us0, device="cuda:0")
     O = _hip.Opts(max_iter=200)
-    Mh = _hip.Model(T=T, Q=Mb.Q, R=Mb.R, Q_terminal=Mb.Qt, x_goal=Mb.x_goal, lower=Mb.lower, upper=Mb.upper)
-    Mu = um.UserModel(um.load("cartpole_user"), T, [0.05, 1.0, 0.1, 1.0, 9.8], Mb.Q, Mb.R, Mb.Qt, Mb.x_goal, None,
-                      Mb.lower, Mb.upper)
+    Mh = _hip.Model(T, Q, R, Qt, xg, None, [-5.0], [5.0])
+    Mu = um.UserModel(um.load("cartpole_user"), T, [0.05, 1.0, 0.1, 1.0, 9.8], Q, R, Qt, xg, None, [-5.0], [5.0])
     a = _hip.solve(Mh, O, dx, du)
     b = um.solve(Mu, O, dx, du)
     same = all(torch.equal(a[k], b[k]) for k in ("xs", "us", "J", "iters", "status"))

@@ -194,3 +194,20 @@ def test_receding_horizon_shift_logic():
         first_us = st.calls[0][1] + 1.0
         expect = np.concatenate([first_us[..., 2:, :], first_us[..., -2:, :]], axis=-2)
         assert np.array_equal(st.calls[1][1], expect)
+
+
+def test_workload_definitions_agree_with_the_checkers():
+    """The benchmark workloads are defined in the package (and bench.py); the CPU checker keeps
+    its own copy of the same definitions: both must produce identical arrays."""
+    from oracle import c_oracle as co
+    from ilqr_amd.synthetic import SyntheticWorkload
+    import bench
+    wl, Mo = SyntheticWorkload(T=30), co.synthetic_model(T=30)
+    for a, b in ((wl.A, Mo.A), (wl.B, Mo.B), (wl.W, Mo.W), (wl.Q, Mo.Q), (wl.R, Mo.R), (wl.Qt, Mo.Qt),
+                 (wl.lower, Mo.lower), (wl.upper, Mo.upper)):
+        assert np.array_equal(a, b)
+    assert (wl.dt, wl.sig_c) == (Mo.dt, Mo.sig_c)
+    for a, b in zip(wl.batch(7), co.synthetic_batch(7, T=30)):
+        assert np.array_equal(a, b)
+    for a, b in zip(bench.make_batch(9, 0), co.cartpole_batch(9)):
+        assert np.array_equal(a, b)
