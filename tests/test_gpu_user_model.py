@@ -110,6 +110,22 @@ def test_user_model_through_the_solver_api(hip):
     assert eq(us1, ref["us"][0]) and len(log) == it_n
 
 
+@pytest.mark.parametrize("B,T,max_iter", [(1, 7, 12), (63, 1, 5), (65, 33, 0), (129, 20, 3)])
+def test_user_model_ragged_batches_and_edge_sizes(hip, B, T, max_iter):
+    """Partly filled wavefronts, a one-step horizon, zero iterations (initial rollout only)."""
+    from ilqr_amd import user_model as um
+    Mo = pendulum(T)
+    x0, us0 = pendulum_batch(B, T, seed=60 + B)
+    ref = co.solve(Mo, co.Opts(max_iter=max_iter), x0, us0, nthreads=4)
+    M = um.UserModel(um.load("pendulum_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower, Mo.upper)
+    out = um.solve(M, hip.Opts(max_iter=max_iter), dev(x0), dev(us0), trace=max_iter > 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+
+
 def test_user_model_rejects_mismatched_dimensions(hip):
     from ilqr_amd import user_model as um
     lib = um.load("pendulum_user")

@@ -105,6 +105,7 @@ def test_user_model_libraries_export_every_declared_symbol():
     declared = set(re.findall(r"\b(ilqr_user_[a-z0-9_]+)\s*\(", body))
     assert declared == {"ilqr_user_dims", "ilqr_user_workspace_bytes", "ilqr_user_solve_batched"}
     for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4)), ("pendulum_fd_user", (3, 4))):
+        um.build_user_model(os.path.join(MODELS, name + ".h"), name)  # hipcc cross-compiles; no-op when up to date
         lib = C.CDLL(um.library_path(name))  # loading needs no GPU
         for sym in declared:
             assert hasattr(lib, sym), (name, sym)
