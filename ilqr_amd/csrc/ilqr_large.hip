@@ -272,12 +272,25 @@ __device__ __forceinline__ double lr_value(const double* H, const double* g, con
     return xg + 0.5 * tot;
 }
 
-// H [64] (LDS, finite and positive definite: the caller has checked), steps: the wave's step table.
+// H [64] (LDS, finite and positive definite: the caller has checked; a copy in registers was measured:
+// what the boxQP gains, the matrix part loses to spills), steps: the wave's step table.
 // On entry Q.x holds the warm start and Q.Lf / Q.rd / Q.fmask the factor of the full H (the caller
 // needed it for the warm start): a factorisation for a free set that Lf already belongs to is not
 // repeated (same inputs, same bits); the reference's counter still counts it.
+#ifdef ILQR_LARGE_QP_PROF // diagnostic build only: shader clocks per part of a boxQP pass, summed over waves
+static __device__ unsigned long long g_lqp[8];
+#define LQP_T(var) long long var = clock64()
+#define LQP_ADD(slot, a, b) lqp_acc[slot] += (unsigned long long)((b) - (a))
+#else
+#define LQP_T(var)
+#define LQP_ADD(slot, a, b)
+#endif
+
 __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps, QPR& Q)
 {
+#ifdef ILQR_LARGE_QP_PROF
+    unsigned long long lqp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     bool cl[LM];
 #pragma unroll
     for (int i = 0; i < LM; ++i) {
@@ -297,6 +310,7 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
             break;
         }
         oldvalue = value;
+        LQP_T(q0);
         double grad[LM];
         bool changed = false;
         int nclamped = 0;
@@ -317,6 +331,8 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
             result = 6;
             break;
         }
+        LQP_T(q1);
+        LQP_ADD(0, q0, q1);
         if (iter == 1 || changed) {
             unsigned mask = 0;
 #pragma unroll
@@ -332,6 +348,8 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
             Q.factored = true;
             ++n_factor;
         }
+        LQP_T(q2);
+        LQP_ADD(1, q1, q2);
         // sla.norm(grad[free]); dnrm2 of a single element is its magnitude
         double ss = 0.0, g1 = 0.0;
         bool first = true;
@@ -348,20 +366,45 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
             break;
         }
         ++n_iter;
+        LQP_T(q3);
+        LQP_ADD(2, q2, q3);
         // grad_clamped = g[free] + H_fc x[clamped]; search[free] = -cho_solve(H_ff, .) - x[free]
+        // (every lane of the wave holds the same problem: the clamped set is wave-uniform, and as
+        // a scalar bit mask it lets the chain skip the unclamped columns instead of computing and
+        // discarding their terms)
         double rhs[LM], search[LM];
+        {
+            unsigned clm = 0;
 #pragma unroll
-        for (int i = 0; i < LM; ++i) {
-            double acc = 0.0;
+            for (int j = 0; j < LM; ++j)
+                clm |= cl[j] ? (1u << j) : 0u;
+            clm = __builtin_amdgcn_readfirstlane(clm);
+            double acc[LM];
+#pragma unroll
+            for (int i = 0; i < LM; ++i)
+                acc[i] = 0.0;
             bool f1 = true;
 #pragma unroll
             for (int j = 0; j < LM; ++j) {
-                double t = f1 ? H[i * LM + j] * Q.x[j] : fma(H[i * LM + j], Q.x[j], acc);
-                acc = cl[j] ? t : acc;
-                f1 = f1 && !cl[j];
+                if (clm & (1u << j)) {
+                    if (f1) {
+#pragma unroll
+                        for (int i = 0; i < LM; ++i)
+                            acc[i] = H[i * LM + j] * Q.x[j];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < LM; ++i)
+                            acc[i] = fma(H[i * LM + j], Q.x[j], acc[i]);
+                    }
+                    f1 = false;
+                }
             }
-            rhs[i] = Q.fr[i] ? Q.g[i] + acc : 0.0;
+#pragma unroll
+            for (int i = 0; i < LM; ++i)
+                rhs[i] = Q.fr[i] ? Q.g[i] + acc[i] : 0.0;
         }
+        LQP_T(q4);
+        LQP_ADD(3, q3, q4);
         if (Q.factored)
             lr_solve(Q.Lf, Q.rd, Q.fr, rhs);
         else
@@ -369,6 +412,8 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
 #pragma unroll
         for (int i = 0; i < LM; ++i)
             search[i] = Q.fr[i] ? rhs[i] * -1 - Q.x[i] : 0.0;
+        LQP_T(q5);
+        LQP_ADD(4, q4, q5);
 
         // Armijo line search (:140-159).  The candidates of the reference's backtracking loop do
         // not depend on each other, so the wave evaluates 64 consecutive trips at once (lane =
@@ -425,7 +470,18 @@ __device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps,
                 break;
             }
         }
+        LQP_T(q6);
+        LQP_ADD(5, q5, q6);
+#ifdef ILQR_LARGE_QP_PROF
+        lqp_acc[6] += 1;
+#endif
     }
+#ifdef ILQR_LARGE_QP_PROF
+    lqp_acc[7] += 1;
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 8; ++q)
+            atomicAdd(&g_lqp[q], lqp_acc[q]);
+#endif
     int nf = 0;
 #pragma unroll
     for (int i = 0; i < LM; ++i)
@@ -1286,6 +1342,16 @@ int ilqr_large_forward_ls(const ilqr_large_model* model, int64_t B, int32_t n_al
                        (int)n_alpha, (int)store_idx, B, xs, us, k, K, J_new, xs_new, us_new);
     return lrc(hipGetLastError());
 }
+
+#ifdef ILQR_LARGE_QP_PROF
+int ilqr_large_debug_qp_phases(unsigned long long* host8, int reset)
+{
+    unsigned long long z[8] = {0};
+    if (reset)
+        return lrc(hipMemcpyToSymbol(HIP_SYMBOL(g_lqp), z, sizeof(z)));
+    return lrc(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_lqp), sizeof(z)));
+}
+#endif
 
 int ilqr_large_debug_profile(void* device_buffer)
 {

@@ -12,6 +12,8 @@ from ilqr_amd import _hip  # noqa: E402
 from ilqr_amd.synthetic import SyntheticWorkload  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+if len(sys.argv) > 2:  # a build with -DILQR_LARGE_QP_PROF: also the parts of a boxQP pass
+    _hip.LIB_PATH = os.path.abspath(sys.argv[2])
 T = 200
 dev = torch.device("cuda:0")
 wl = SyntheticWorkload(T=T)
@@ -22,8 +24,19 @@ xs, _ = _hip.large_rollout_cost(M, x0, us)
 mu = torch.ones(B, dtype=torch.float64, device=dev)
 buf = torch.zeros((B, 8), dtype=torch.int64, device=dev)
 _hip.check(_hip.lib().ilqr_large_debug_profile(C.c_void_p(buf.data_ptr())))
+qp_parts = hasattr(_hip.lib(), "ilqr_large_debug_qp_phases")
+if qp_parts:
+    _hip.lib().ilqr_large_debug_qp_phases(None, 1)
 _hip.large_backward(M, _hip.Opts(), xs, us, mu, want_masks=False)
 torch.cuda.synchronize()
+if qp_parts:
+    acc = (C.c_ulonglong * 8)()
+    _hip.lib().ilqr_large_debug_qp_phases(acc, 0)
+    names = ["gradient + classification", "factorisation", "gradient norm", "clamped right-hand side", "solve + search",
+             "line search (64 trips at once)"]
+    print("boxQP passes %d in %d calls; shader clocks per pass:" % (acc[6], acc[7]))
+    for nm, v in zip(names, acc):
+        print("   %-32s %7.0f" % (nm, v / max(1, acc[6])))
 _hip.check(_hip.lib().ilqr_large_debug_profile(None))
 p = buf.cpu().numpy().astype(np.float64)
 per = p[:, :3] / p[:, 3:4]
