@@ -538,7 +538,20 @@ __device__ __forceinline__ void qp_count(int slot)
         atomicAdd(&g_qp_prof[slot], 1ull);
 }
 #define QP_COUNT(slot) qp_count(slot)
+// per-wave counts (index: global wavefront number of a 1-D launch): [0] literal-loop fallbacks,
+// [1] calls in which some lane's candidate was rejected
+static __device__ unsigned int g_qp_wave[2][8192];
+__device__ __forceinline__ void qp_count_wave(int slot)
+{
+    if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) {
+        unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (w < 8192u)
+            atomicAdd(&g_qp_wave[slot][w], 1u);
+    }
+}
+#define QP_COUNT_WAVE(slot) qp_count_wave(slot)
 #else
+#define QP_COUNT_WAVE(slot)
 #define QP_COUNT(slot)
 #endif
 
@@ -818,6 +831,7 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
     slow = slow | (act0 & s);
     bool exh0 = false;
     if (__ballot(act0 & rej0) != 0ull) {
+        QP_COUNT_WAVE(1);
         double xl, vl;
         s = false;
         bool ex = qp_exhausts(O, H, g, lo, hi, xa, search0, grad0, s, xl, vl);
@@ -865,6 +879,7 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
     QP_COUNT(9);
     if (__ballot(slow) != 0ull) {
         QP_COUNT(7);
+        QP_COUNT_WAVE(0);
         boxqp1_loop(O, tab, H, sqrtH, rsqrtH, g, lo, hi, x0, out);
         return;
     }

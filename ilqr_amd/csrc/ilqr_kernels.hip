@@ -1515,6 +1515,17 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
 }
 
 #ifdef ILQR_QP_PROF
+int ilqr_debug_qp_wave(unsigned int* host2x8192, int reset)
+{
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ilqr::g_qp_wave)) != hipSuccess)
+            return ILQR_ERR_HIP;
+        return hip_status(hipMemset(p, 0, sizeof(unsigned int) * 2 * 8192));
+    }
+    return hip_status(hipMemcpyFromSymbol(host2x8192, HIP_SYMBOL(ilqr::g_qp_wave), sizeof(unsigned int) * 2 * 8192));
+}
+
 int ilqr_debug_qp_prof(unsigned long long* host16, int reset)
 {
     unsigned long long z[16] = {0};

@@ -7,6 +7,8 @@ from ilqr_amd import _hip
 import bench
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+if len(sys.argv) > 2:  # a build with -DILQR_QP_PROF: also boxQP fallback counts per wave
+    _hip.LIB_PATH = os.path.abspath(sys.argv[2])
 dev = torch.device("cuda:0")
 Q, R, Qt, xg = bench.cartpole_cost()
 M = _hip.Model(100, Q, R, Qt, xg, None, [-5.0], [5.0])
@@ -17,7 +19,14 @@ log = torch.zeros((nw, 4), dtype=torch.int64, device=dev)
 O = _hip.Opts()
 _hip.solve(M, O, x0, us); torch.cuda.synchronize()
 _hip.check(_hip.lib().ilqr_debug_wave_log(C.c_void_p(log.data_ptr())))
+qp_wave = hasattr(_hip.lib(), "ilqr_debug_qp_wave")
+if qp_wave:
+    _hip.lib().ilqr_debug_qp_wave(None, 1)
 res = _hip.solve(M, O, x0, us); torch.cuda.synchronize()
+if qp_wave:
+    qw = (C.c_uint * (2 * 8192))()
+    _hip.lib().ilqr_debug_qp_wave(qw, 0)
+    qw = np.array(qw[:]).reshape(2, 8192)[:, :nw]
 _hip.check(_hip.lib().ilqr_debug_wave_log(None))
 L = log.cpu().numpy()
 t0 = L[:, 0].min()
@@ -49,3 +58,16 @@ xcc = L[:, 3]
 print("waves per XCC:", np.bincount(xcc.astype(int)))
 q = np.percentile(life, [5, 25, 50, 75, 95, 100])
 print("life percentiles 5/25/50/75/95/100: " + " ".join("%.1f" % v for v in q))
+
+if qp_wave:
+    life_ = end - start
+    print("boxQP literal-loop fallbacks per wave: mean %.0f max %d; rejected-candidate blocks: mean %.0f max %d"
+          % (qw[0].mean(), qw[0].max(), qw[1].mean(), qw[1].max()))
+    print("correlation of wave life with fallbacks %.2f, with rejected-candidate blocks %.2f"
+          % (np.corrcoef(life_, qw[0])[0, 1], np.corrcoef(life_, qw[1])[0, 1]))
+    order = np.argsort(-life_)[:5]
+    for w in order:
+        print("   wave %4d life %.1f ms: fallbacks %d, rejected blocks %d" % (w, life_[w], qw[0][w], qw[1][w]))
+    A_ = np.stack([np.ones(nw), qw[0], qw[1]], 1)
+    coef = np.linalg.lstsq(A_, life_, rcond=None)[0]
+    print("least squares: life = %.1f ms + %.2f us per fallback + %.2f us per rejected block" % (coef[0], coef[1] * 1e3, coef[2] * 1e3))
