@@ -12,6 +12,7 @@
 
 #include "../../include/ilqr_hip.h"
 #include "ilqr_device.hpp"
+#include "ilqr_qp_dense.hpp"
 
 using namespace ilqr;
 
@@ -804,69 +805,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
 
 // ------------------------------------------------------- stand-alone boxQP
 
-constexpr int QM = 8; // largest boxQP dimension of the stand-alone kernel
-
-// (v^T M) . v, ilqr_boxQP.py:62
-__device__ double qpg_quad(int m, const double* v, const double* M)
-{
-    double tot = 0.0;
-    for (int j = 0; j < m; ++j) {
-        double acc = v[0] * M[j];
-        for (int i = 1; i < m; ++i)
-            acc = fma(v[i], M[i * m + j], acc);
-        tot = (j == 0) ? acc * v[0] : fma(acc, v[j], tot);
-    }
-    return tot;
-}
-
-__device__ double qpg_value(int m, const double* H, const double* g, const double* x)
-{
-    double xg = x[0] * g[0];
-    for (int i = 1; i < m; ++i)
-        xg = fma(x[i], g[i], xg);
-    return xg + 0.5 * qpg_quad(m, x, H);
-}
-
-// Lower Cholesky of the leading d x d block (row stride ld_); 0 ok, 1 = pivot not > 0.
-__device__ int qpg_chol(int d, const double* A, int lda, double* L, int ldl)
-{
-    for (int j = 0; j < d; ++j) {
-        double s = A[j * lda + j];
-        for (int k = 0; k < j; ++k)
-            s = fma(-L[j * ldl + k], L[j * ldl + k], s);
-        if (!(s > 0.0))
-            return 1;
-        double d_jj = sqrt(s);
-        double r_jj = 1.0 / d_jj;
-        L[j * ldl + j] = d_jj;
-        for (int i = j + 1; i < d; ++i) {
-            double t = A[i * lda + j];
-            for (int k = 0; k < j; ++k)
-                t = fma(-L[i * ldl + k], L[j * ldl + k], t);
-            L[i * ldl + j] = t * r_jj;
-        }
-    }
-    return 0;
-}
-
-// Solve (L L^T) x = b in place, multiplying by reciprocal diagonals.
-__device__ void qpg_solve(int d, const double* L, int ldl, double* b)
-{
-    for (int i = 0; i < d; ++i) {
-        double s = b[i];
-        for (int j = 0; j < i; ++j)
-            s = fma(-L[i * ldl + j], b[j], s);
-        b[i] = s * (1.0 / L[i * ldl + i]);
-    }
-    for (int i = d - 1; i >= 0; --i) {
-        double s = b[i];
-        for (int j = i + 1; j < d; ++j)
-            s = fma(-L[j * ldl + i], b[j], s);
-        b[i] = s * (1.0 / L[i * ldl + i]);
-    }
-}
-
-// boxQP (ilqr_boxQP.py:9-186) for m <= 8, one QP per lane, ref layout.
+// boxQP (ilqr_boxQP.py:9-186) for m <= 8, one QP per lane, ref layout (boxqp_dense).
 __global__ __launch_bounds__(WAVE) void k_boxqp(QPOptsP O, int64_t B, int m, const double* __restrict__ Hg,
                                                 const double* __restrict__ gg,
                                                 const double* __restrict__ lowerg,
@@ -880,140 +819,28 @@ __global__ __launch_bounds__(WAVE) void k_boxqp(QPOptsP O, int64_t B, int m, con
     if (q >= B)
         return;
     double H[QM * QM], g[QM], lower[QM], upper[QM], x[QM], Hff[QM * QM];
-    double grad[QM], search[QM], xc[QM], rhs[QM], sub[QM * QM], Lfull[QM * QM];
-    int clamped[QM], freev[QM], oldclamped[QM], fidx[QM], cidx[QM];
-    for (int i = 0; i < m * m; ++i) {
-        H[i] = Hg[q * m * m + i];
-        Hff[i] = 1.0; // H_ff = np.ones((n, n)), :36
-    }
-    bool h_finite = true;
+    int freev[QM];
     for (int i = 0; i < m * m; ++i)
-        h_finite = h_finite && (fabs(H[i]) < __builtin_inf());
+        H[i] = Hg[q * m * m + i];
     for (int i = 0; i < m; ++i) {
         g[i] = gg[q * m + i];
         lower[i] = lowerg[q * m + i];
         upper[i] = upperg[q * m + i];
-        clamped[i] = 0;
-        freev[i] = 0;
-        x[i] = x0g ? clamp1(lower[i], upper[i], x0g[q * m + i]) : (lower[i] + upper[i]) / 2;
+        x[i] = x0g ? x0g[q * m + i] : 0.0;
     }
-    double value = qpg_value(m, H, g, x), oldvalue = 0.0;
-    int result = -1, hd = m, n_iter = 0, n_factor = 0, n_bt = 0;
-    bool h_pd = h_finite && qpg_chol(m, H, m, Lfull, m) == 0;
-    bool linalg = false;
-
-    for (int iter = 0; iter < O.max_iter; ++iter) {
-        if (result != -1)
-            break;
-        if (iter > 1 && (oldvalue - value) < O.min_rel * fabs(oldvalue) && (oldvalue - value) > 0.0) {
-            result = 4;
-            break;
-        }
-        oldvalue = value;
-        for (int i = 0; i < m; ++i) {
-            double acc = H[i * m] * x[0];
-            for (int j = 1; j < m; ++j)
-                acc = fma(H[i * m + j], x[j], acc);
-            grad[i] = g[i] + acc;
-        }
-        int nclamped = 0;
-        for (int i = 0; i < m; ++i) {
-            oldclamped[i] = clamped[i];
-            clamped[i] = ((x[i] == lower[i]) && (grad[i] > 0.0)) || ((x[i] == upper[i]) && (grad[i] < 0.0));
-            freev[i] = !clamped[i];
-            nclamped += clamped[i];
-        }
-        if (nclamped == m) {
-            result = 6;
-            break;
-        }
-        if (!h_finite) { // eigvals raises LinAlgError
-            linalg = true;
-            break;
-        }
-        if (!h_pd) {
-            result = -1;
-            break;
-        }
-        bool factorize = iter == 1;
-        for (int i = 0; i < m; ++i)
-            factorize = factorize || (oldclamped[i] != clamped[i]);
-        int nf = 0, nc = 0;
-        for (int i = 0; i < m; ++i) {
-            if (freev[i])
-                fidx[nf++] = i;
-            else
-                cidx[nc++] = i;
-        }
-        if (factorize) {
-            for (int a = 0; a < nf; ++a)
-                for (int b = 0; b < nf; ++b)
-                    sub[a * m + b] = H[fidx[a] * m + fidx[b]];
-            if (qpg_chol(nf, sub, m, Hff, m) != 0) {
-                linalg = true;
-                break;
-            }
-            hd = nf;
-            ++n_factor;
-        }
-        double ss = 0.0;
-        for (int a = 0; a < nf; ++a)
-            ss = (a == 0) ? grad[fidx[0]] * grad[fidx[0]] : fma(grad[fidx[a]], grad[fidx[a]], ss);
-        double gnorm = nf == 1 ? fabs(grad[fidx[0]]) : sqrt(ss);
-        if (gnorm < O.min_grad) {
-            result = 5;
-            break;
-        }
-        ++n_iter;
-        for (int a = 0; a < nf; ++a) {
-            double acc = 0.0;
-            for (int b = 0; b < nc; ++b)
-                acc = (b == 0) ? H[fidx[a] * m + cidx[0]] * x[cidx[0]]
-                               : fma(H[fidx[a] * m + cidx[b]], x[cidx[b]], acc);
-            rhs[a] = g[fidx[a]] + acc;
-        }
-        qpg_solve(nf, Hff, m, rhs);
-        for (int i = 0; i < m; ++i)
-            search[i] = 0.0;
-        for (int a = 0; a < nf; ++a)
-            search[fidx[a]] = rhs[a] * -1 - x[fidx[a]];
-
-        double step = 1.0;
-        for (int i = 0; i < m; ++i)
-            xc[i] = clamp1(lower[i], upper[i], x[i] + step * search[i]);
-        double sdotg = (xc[0] - x[0]) * grad[0];
-        for (int i = 1; i < m; ++i)
-            sdotg = sdotg + (xc[i] - x[i]) * grad[i];
-        double vc = qpg_value(m, H, g, xc);
-        while ((vc - oldvalue) / (sdotg + 1e-10) < O.armijo) {
-            step = step * O.step_dec;
-            ++n_bt;
-            for (int i = 0; i < m; ++i)
-                xc[i] = clamp1(lower[i], upper[i], x[i] + step * search[i]);
-            vc = qpg_value(m, H, g, xc);
-            sdotg = (xc[0] - x[0]) * grad[0];
-            for (int i = 1; i < m; ++i)
-                sdotg = sdotg + (xc[i] - x[i]) * grad[i];
-            if (step < O.min_step) {
-                result = 2;
-                break;
-            }
-        }
-        for (int i = 0; i < m; ++i)
-            x[i] = xc[i];
-        value = vc;
-    }
+    QPDenseOut r;
+    boxqp_dense(O, m, H, g, lower, upper, x0g != nullptr, x, Hff, freev, r);
     for (int i = 0; i < m; ++i) {
         xg_out[q * m + i] = x[i];
         free_out[q * m + i] = freev[i];
     }
     for (int i = 0; i < m * m; ++i)
         Hff_out[q * m * m + i] = Hff[i];
-    result_out[q] = linalg ? -99 : result; // -99: the reference would raise LinAlgError
-    hd_out[q] = hd;
-    cnt_out[q * 3 + 0] = n_iter;
-    cnt_out[q * 3 + 1] = n_factor;
-    cnt_out[q * 3 + 2] = n_bt;
+    result_out[q] = r.linalg ? -99 : r.result; // -99: the reference would raise LinAlgError
+    hd_out[q] = r.hd;
+    cnt_out[q * 3 + 0] = r.n_iter;
+    cnt_out[q * 3 + 1] = r.n_factor;
+    cnt_out[q * 3 + 2] = r.n_bt;
 }
 
 // boxQP for m = 1 through the same in-register routine the backward pass uses.

@@ -1,5 +1,5 @@
-// User-defined dynamics for the batched control-limited iLQR solve (single control, up to 8
-// states).  The reference gets its generality from Python callbacks (AutogradDynamics /
+// User-defined dynamics for the batched control-limited iLQR solve (up to 8 states; one control
+// on the fast path, 2..4 controls on a general path, see ILQR_USER_M below).  The reference gets its generality from Python callbacks (AutogradDynamics /
 // FiniteDifferenceDynamics, ilqr/ilqr_dynamics.py:94-575), which cannot run inside a kernel;
 // here a model is a small C source with two functions,
 //
@@ -25,6 +25,7 @@
 #include "../../include/ilqr_hip.h"
 #include "../../include/ilqr_user.h"
 #include "ilqr_device.hpp"
+#include "ilqr_qp_dense.hpp"
 
 #define ILQR_FN __device__ __forceinline__
 #define ilqr_sincos(x, s, c) ilqr::det_sincos((x), *(s), *(c))
@@ -34,6 +35,9 @@
 #error "compile with -DILQR_USER_MODEL='\"path/to/model.h\"'"
 #endif
 #include ILQR_USER_MODEL
+#ifndef ILQR_USER_M
+#define ILQR_USER_M 1 // controls; with more than one, u is passed to the model as a pointer
+#endif
 #include "../../include/ilqr_user_fd.h" // ilqr_user_jac by forward differences if the model asks for it
 
 namespace {
@@ -41,12 +45,19 @@ namespace {
 using namespace ilqr;
 
 constexpr int UN = ILQR_USER_N;
+constexpr int UM = ILQR_USER_M;
 constexpr int UNP = ILQR_USER_NP > 0 ? ILQR_USER_NP : 1;
 static_assert(UN >= 1 && UN <= 8, "ILQR_USER_N must be between 1 and 8");
+static_assert(UM >= 1 && UM <= 4, "ILQR_USER_M must be between 1 and 4");
 
 struct UParams {
     double p[UNP];
 };
+
+// rows of 64 doubles in one wavefront's workspace tile: two copies of xs, us, k, K
+__host__ __device__ inline int64_t utile_rows(int64_t T) { return 2 * ((T + 1) * UN + T * UM + T * UM + T * UM * UN); }
+
+#if ILQR_USER_M == 1
 struct UCost { // QRCost, ilqr/ilqr_cost.py:490-530, m = 1
     double Q[UN * UN], Qt[UN * UN], QQ[UN * UN], QQt[UN * UN];
     double R, RR, xg[UN], ug;
@@ -326,8 +337,6 @@ struct UWork {
     double *xs0, *xs1, *us0, *us1, *k0, *k1, *K0, *K1;
 };
 
-__host__ __device__ inline int64_t utile_rows(int64_t T) { return 2 * ((T + 1) * UN + T + T + T * UN); }
-
 __device__ __forceinline__ UWork utile(double* ws, int64_t tile, int64_t T)
 {
     double* p = ws + tile * utile_rows(T) * 64;
@@ -554,11 +563,466 @@ __global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C, SolveOpts
 #undef KG
 }
 
+#else // ---------------------------------------------------------------- more than one control
+
+// The general case, 2 <= m <= 4: a direct per-lane evaluation of _backward_pass / _compute_Q_terms /
+// _forward_pass (ilqr_core.py:85-228) with every term of every np.dot as a left-to-right chain, the
+// dense boxQP (boxqp_dense), and the serial first-hit line search.  Written for generality, not
+// speed: the per-problem matrices of the larger sizes live partly in scratch memory.
+
+struct GCost { // QRCost, ilqr/ilqr_cost.py:490-530
+    double Q[UN * UN], Qt[UN * UN], R[UM * UM], xg[UN], ug[UM];
+};
+struct GBounds {
+    double lo[UM], hi[UM];
+};
+
+template <int R>
+__device__ __forceinline__ void gload(const double* base, int64_t row0, int64_t b, double* v)
+{
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        v[i] = base[(row0 + i) * 64 + b];
+}
+template <int R>
+__device__ __forceinline__ void gstore(double* base, int64_t row0, int64_t b, const double* v)
+{
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        base[(row0 + i) * 64 + b] = v[i];
+}
+
+// QRCost.l, ilqr_cost.py:532-553 (the value carries the 1/2 its gradients lack)
+__device__ inline double gcost_l(const GCost& C, const double* x, const double* u, bool terminal)
+{
+    double xd[UN], ud[UM];
+    for (int a = 0; a < UN; ++a)
+        xd[a] = x[a] - C.xg[a];
+    double sx = qpg_quad(UN, xd, terminal ? C.Qt : C.Q) * 0.5;
+    if (terminal)
+        return sx;
+    for (int a = 0; a < UM; ++a)
+        ud[a] = u[a] - C.ug[a];
+    double su = qpg_quad(UM, ud, C.R) * 0.5;
+    return sx + su;
+}
+// l_x = x_diff^T (Q + Q^T), ilqr_cost.py:555-569
+__device__ inline void gcost_lx(const GCost& C, const double* x, bool terminal, double* out)
+{
+    const double* Qm = terminal ? C.Qt : C.Q;
+    double xd[UN];
+    for (int a = 0; a < UN; ++a)
+        xd[a] = x[a] - C.xg[a];
+    for (int j = 0; j < UN; ++j) {
+        double acc = xd[0] * (Qm[j] + Qm[j * UN]);
+        for (int a = 1; a < UN; ++a)
+            acc = fma(xd[a], Qm[a * UN + j] + Qm[j * UN + a], acc);
+        out[j] = acc;
+    }
+}
+
+struct GAcc {
+    double Vx[UN], Vxx[UN * UN];
+    double dJ1, dJ2;
+    int qp_iter, qp_backtrack, n_clamped;
+};
+
+// One step of _backward_pass (ilqr_core.py:127-176) with _compute_Q_terms (:179-228).
+__device__ int gbw_step(const UParams& P, const GCost& C, const QPOptsP& QO, const GBounds& bd, const double* x,
+                        const double* u, double mu, GAcc& S, double* ki, double* Ki)
+{
+    constexpr int n = UN, m = UM;
+    double fx[n * n], fu[n * m], lx[n], lu[m];
+    double Qx[n], Qu[m], Qxx[n * n], Qux[m * n], Quu[m * m], M1[n * n], M2[m * n], L[m * m], Hff[m * m], T1[n * m];
+    const double* Vx = S.Vx;
+    const double* Vxx = S.Vxx;
+    ilqr_user_jac(P.p, x, u, fx, fu);
+    gcost_lx(C, x, false, lx);
+    {   // l_u = u_diff^T (R + R^T), ilqr_cost.py:571-587
+        double ud[m];
+        for (int a = 0; a < m; ++a)
+            ud[a] = u[a] - C.ug[a];
+        for (int j = 0; j < m; ++j) {
+            double acc = ud[0] * (C.R[j] + C.R[j * m]);
+            for (int a = 1; a < m; ++a)
+                acc = fma(ud[a], C.R[a * m + j] + C.R[j * m + a], acc);
+            lu[j] = acc;
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        double acc = fx[j] * Vx[0];
+        for (int a = 1; a < n; ++a)
+            acc = fma(fx[a * n + j], Vx[a], acc);
+        Qx[j] = lx[j] + acc;
+    }
+    for (int j = 0; j < m; ++j) {
+        double acc = fu[j] * Vx[0];
+        for (int a = 1; a < n; ++a)
+            acc = fma(fu[a * m + j], Vx[a], acc);
+        Qu[j] = lu[j] + acc;
+    }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            double acc = fx[a] * Vxx[b];
+            for (int c = 1; c < n; ++c)
+                acc = fma(fx[c * n + a], Vxx[c * n + b], acc);
+            M1[a * n + b] = acc;
+        }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            double acc = M1[a * n] * fx[b];
+            for (int c = 1; c < n; ++c)
+                acc = fma(M1[a * n + c], fx[c * n + b], acc);
+            Qxx[a * n + b] = (C.Q[a * n + b] + C.Q[b * n + a]) + acc;
+        }
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < n; ++b) { // reg = V_xx + mu I
+            double acc = fu[a] * (Vxx[b] + mu * (b == 0 ? 1.0 : 0.0));
+            for (int c = 1; c < n; ++c)
+                acc = fma(fu[c * m + a], Vxx[c * n + b] + mu * (c == b ? 1.0 : 0.0), acc);
+            M2[a * n + b] = acc;
+        }
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < n; ++b) {
+            double acc = M2[a * n] * fx[b];
+            for (int c = 1; c < n; ++c)
+                acc = fma(M2[a * n + c], fx[c * n + b], acc);
+            Qux[a * n + b] = 0.0 + acc;
+        }
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < m; ++b) {
+            double acc = M2[a * n] * fu[b];
+            for (int c = 1; c < n; ++c)
+                acc = fma(M2[a * n + c], fu[c * m + b], acc);
+            Quu[a * m + b] = (C.R[a * m + b] + C.R[b * m + a]) + acc;
+        }
+    // np.all(np.linalg.eigvals(Q_uu) > 0) else print / warn / break, then cholesky   (:137-141)
+    for (int a = 0; a < m * m; ++a)
+        if (!(fabs(Quu[a]) < __builtin_inf()))
+            return BW_LINALG;
+    if (qpg_chol(m, Quu, m, L, m) != 0)
+        return BW_NOT_PD;
+    // k[i] = cho_solve((R_Q_uu, True), Q_u): the (positive-sign) boxQP warm start   (:145)
+    double xq[m], lo[m], hi[m];
+    int freev[m];
+    for (int a = 0; a < m; ++a) {
+        xq[a] = Qu[a];
+        lo[a] = bd.lo[a] - u[a];
+        hi[a] = bd.hi[a] - u[a];
+    }
+    qpg_solve(m, L, m, xq);
+    QPDenseOut qr;
+    boxqp_dense(QO, m, Quu, Qu, lo, hi, true, xq, Hff, freev, qr);
+    if (qr.linalg)
+        return BW_LINALG;
+    S.qp_iter += qr.n_iter;
+    S.qp_backtrack += qr.n_bt;
+    int nf = 0, fidx[m];
+    for (int a = 0; a < m; ++a) {
+        ki[a] = xq[a];
+        if (freev[a])
+            fidx[nf++] = a;
+    }
+    S.n_clamped += nf < m ? 1 : 0;
+    // K[i, free, :] = -cho_solve((H_ff, True), Q_ux[free, :]); clamped rows stay 0   (:157-160)
+    for (int a = 0; a < m * n; ++a)
+        Ki[a] = 0.0;
+    if (nf > 0) {
+        double col[m];
+        for (int b = 0; b < n; ++b) {
+            for (int a = 0; a < nf; ++a)
+                col[a] = Qux[fidx[a] * n + b];
+            qpg_solve(nf, Hff, m, col);
+            for (int a = 0; a < nf; ++a)
+                Ki[fidx[a] * n + b] = col[a] * -1;
+        }
+    }
+    // V_x, V_xx (:164-169), Delta_J (:175-176)
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < m; ++b) {
+            double acc = Ki[a] * Quu[b];
+            for (int c = 1; c < m; ++c)
+                acc = fma(Ki[c * n + a], Quu[c * m + b], acc);
+            T1[a * m + b] = acc;
+        }
+    double Vxn[n], Vn[n * n];
+    for (int a = 0; a < n; ++a) {
+        double t1 = T1[a * m] * ki[0], t2 = Ki[a] * Qu[0], t3 = Qux[a] * ki[0];
+        for (int c = 1; c < m; ++c) {
+            t1 = fma(T1[a * m + c], ki[c], t1);
+            t2 = fma(Ki[c * n + a], Qu[c], t2);
+            t3 = fma(Qux[c * n + a], ki[c], t3);
+        }
+        Vxn[a] = ((Qx[a] + t1) + t2) + t3;
+    }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            double t1 = T1[a * m] * Ki[b], t2 = Ki[a] * Qux[b], t3 = Qux[a] * Ki[b];
+            for (int c = 1; c < m; ++c) {
+                t1 = fma(T1[a * m + c], Ki[c * n + b], t1);
+                t2 = fma(Ki[c * n + a], Qux[c * n + b], t2);
+                t3 = fma(Qux[c * n + a], Ki[c * n + b], t3);
+            }
+            Vn[a * n + b] = ((Qxx[a * n + b] + t1) + t2) + t3;
+        }
+    for (int a = 0; a < n; ++a)
+        S.Vx[a] = Vxn[a];
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b)
+            S.Vxx[a * n + b] = 0.5 * (Vn[a * n + b] + Vn[b * n + a]);
+    double d1 = ki[0] * Qu[0];
+    for (int c = 1; c < m; ++c)
+        d1 = fma(ki[c], Qu[c], d1);
+    double d2 = 0.0;
+    for (int a = 0; a < m; ++a) {
+        double acc = Quu[a * m] * ki[0];
+        for (int c = 1; c < m; ++c)
+            acc = fma(Quu[a * m + c], ki[c], acc);
+        d2 = (a == 0) ? ki[0] * acc : fma(ki[a], acc, d2);
+    }
+    S.dJ1 = S.dJ1 + d1;
+    S.dJ2 = S.dJ2 + d2 * 0.5;
+    return BW_OK;
+}
+
+// One backward sweep; gains of the steps it does not reach are zero (np.zeros_like, :118-119).
+__device__ int gbackward(const UParams& P, const GCost& C, const QPOptsP& QO, const GBounds& bd, int T, int64_t b,
+                         const double* xs, const double* us, double mu, double* k, double* K, GAcc& S, int& stopped_at)
+{
+    double xT[UN];
+    gload<UN>(xs, (int64_t)T * UN, b, xT);
+    gcost_lx(C, xT, true, S.Vx);
+    for (int a = 0; a < UN; ++a)
+        for (int c = 0; c < UN; ++c)
+            S.Vxx[a * UN + c] = C.Qt[a * UN + c] + C.Qt[c * UN + a];
+    S.dJ1 = 0.0;
+    S.dJ2 = 0.0;
+    S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+    stopped_at = -1;
+    int rc = BW_OK;
+    for (int i = T - 1; i >= 0; --i) {
+        double ki[UM], Ki[UM * UN];
+        for (int a = 0; a < UM; ++a)
+            ki[a] = 0.0;
+        for (int a = 0; a < UM * UN; ++a)
+            Ki[a] = 0.0;
+        if (rc == BW_OK) {
+            double x[UN], u[UM], kt[UM], Kt[UM * UN];
+            gload<UN>(xs, (int64_t)i * UN, b, x);
+            gload<UM>(us, (int64_t)i * UM, b, u);
+            int r = gbw_step(P, C, QO, bd, x, u, mu, S, kt, Kt);
+            if (r == BW_OK) {
+                for (int a = 0; a < UM; ++a)
+                    ki[a] = kt[a];
+                for (int a = 0; a < UM * UN; ++a)
+                    Ki[a] = Kt[a];
+            } else {
+                rc = r;
+                if (r == BW_NOT_PD)
+                    stopped_at = i;
+            }
+        }
+        gstore<UM>(k, (int64_t)i * UM, b, ki);
+        gstore<UM * UN>(K, (int64_t)i * UM * UN, b, Ki);
+    }
+    return rc;
+}
+
+// _forward_pass + _trajectory_cost (ilqr_core.py:85-107, :230-239); k == nullptr: plain rollout of us.
+__device__ double gforward(const UParams& P, const GCost& C, int T, int64_t b, const double* xs, const double* us,
+                           const double* k, const double* K, double alpha, const double* x0, double* xs_new,
+                           double* us_new)
+{
+    double xn[UN], xt[UN];
+    gload<UN>(x0, 0, b, xn);
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double un[UM];
+        gload<UM>(us, (int64_t)t * UM, b, un);
+        if (k != nullptr) {
+            double xo[UN], dx[UN], kt[UM], Kt[UM * UN];
+            gload<UN>(xs, (int64_t)t * UN, b, xo);
+            gload<UM>(k, (int64_t)t * UM, b, kt);
+            gload<UM * UN>(K, (int64_t)t * UM * UN, b, Kt);
+            for (int a = 0; a < UN; ++a)
+                dx[a] = xn[a] - xo[a];
+            for (int j = 0; j < UM; ++j) {
+                double acc = Kt[j * UN] * dx[0];
+                for (int a = 1; a < UN; ++a)
+                    acc = fma(Kt[j * UN + a], dx[a], acc);
+                un[j] = (un[j] + alpha * kt[j]) + acc; // never clamped (:104)
+            }
+        }
+        if (xs_new != nullptr) {
+            gstore<UN>(xs_new, (int64_t)t * UN, b, xn);
+            gstore<UM>(us_new, (int64_t)t * UM, b, un);
+        }
+        J = J + gcost_l(C, xn, un, false);
+        ilqr_user_f(P.p, xn, un, xt);
+        for (int a = 0; a < UN; ++a)
+            xn[a] = xt[a];
+    }
+    if (xs_new != nullptr)
+        gstore<UN>(xs_new, (int64_t)T * UN, b, xn);
+    return J + gcost_l(C, xn, nullptr, true);
+}
+
+struct UWork {
+    double *xs0, *xs1, *us0, *us1, *k0, *k1, *K0, *K1;
+};
+__device__ __forceinline__ UWork utile(double* ws, int64_t tile, int64_t T)
+{
+    double* p = ws + tile * utile_rows(T) * 64;
+    UWork W;
+    W.xs0 = p;
+    W.xs1 = W.xs0 + (T + 1) * UN * 64;
+    W.us0 = W.xs1 + (T + 1) * UN * 64;
+    W.us1 = W.us0 + T * UM * 64;
+    W.k0 = W.us1 + T * UM * 64;
+    W.k1 = W.k0 + T * UM * 64;
+    W.K0 = W.k1 + T * UM * 64;
+    W.K1 = W.K0 + T * UM * UN * 64;
+    return W;
+}
+
+// iLQR.update_u (ilqr_core.py:241-399), every lane its own problem, serial first-hit line search.
+__global__ __launch_bounds__(64) void k_user_solve_m(UParams P, GCost C, SolveOptsP O, GBounds bd, int T, int64_t B,
+                                                     double* ws, const double* x0, const double* us_init,
+                                                     double* delta_io, double* k_io, double* K_io, double* xs_out,
+                                                     double* us_out, double* J_out, double* mu_out,
+                                                     int32_t* iters_out, int32_t* status_out, ilqr_trace tr)
+{
+    const int lane = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    if (b >= B)
+        return;
+    const UWork W = utile(ws, blockIdx.x, T);
+    const int64_t bl = lane;
+#define XS(i) ((i) ? W.xs1 : W.xs0)
+#define US(i) ((i) ? W.us1 : W.us0)
+#define KF(i) ((i) ? W.k1 : W.k0)
+#define KG(i) ((i) ? W.K1 : W.K0)
+    for (int i = 0; i < UN; ++i)
+        W.xs0[(int64_t)i * 64 + bl] = x0[b * UN + i];
+    for (int t = 0; t < T; ++t) {
+        for (int j = 0; j < UM; ++j) {
+            W.us0[((int64_t)t * UM + j) * 64 + bl] = us_init[(b * T + t) * UM + j];
+            W.k0[((int64_t)t * UM + j) * 64 + bl] = k_io[(b * T + t) * UM + j];
+        }
+        for (int i = 0; i < UM * UN; ++i)
+            W.K0[((int64_t)t * UM * UN + i) * 64 + bl] = K_io[(b * T + t) * UM * UN + i];
+    }
+    const QPOptsP& QO = O.qp;
+    int cur = 0, gcur = 0;
+    double mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
+    double delta = delta_io[b];
+    // initial rollout and cost (:269-271)
+    double J = gforward(P, C, T, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
+    double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
+    int status = ILQR_RAN_OUT, iters = 0;
+    for (int it = 0; it < O.max_iter; ++it) {
+        GAcc S;
+        int stopped_at = -1;
+        S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+        // backward pass with the LinAlgError retry loop (:287-299)
+        for (;;) {
+            int gnew = gcur ^ 1;
+            int rc = gbackward(P, C, QO, bd, T, bl, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S, stopped_at);
+            if (rc != BW_LINALG) {
+                gcur = gnew;
+                dJ1 = S.dJ1;
+                dJ2 = S.dJ2;
+                break;
+            }
+            delta = fmax(delta, 1.0) * O.delta0;
+            mu = fmax(O.mu_min, mu * delta);
+            if (O.mu_max != 0.0 && mu >= O.mu_max)
+                break;
+        }
+        // line search: the serial first-hit scan (:301-313)
+        int accepted = 0, j = 0;
+        double Jnew = 0.0;
+        const int nxt = cur ^ 1;
+        for (j = 0; j < O.n_alpha; ++j) {
+            double alpha = O.alphas[j];
+            Jnew = gforward(P, C, T, bl, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
+            double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+            if (expected <= 0.0)
+                break;
+            if ((J - Jnew) / expected > O.scale) {
+                actual = J - Jnew;
+                accepted = 1;
+                break;
+            }
+        }
+        bool stop = false;
+        int converged = 0;
+        if (accepted) {
+            delta = fmin(1.0, delta) / O.delta0;
+            mu = mu * delta;
+            if (mu <= O.mu_min)
+                mu = 0.0;
+            J = Jnew;
+            cur = nxt;
+            if (actual < O.tol)
+                converged = 1;
+        } else {
+            delta = fmax(delta, 1.0) * O.delta0;
+            mu = fmax(O.mu_min, mu * delta);
+            if (O.mu_max != 0.0 && mu >= O.mu_max) {
+                status = ILQR_MU_MAX;
+                stop = true;
+            }
+        }
+        int64_t to = (int64_t)it * B + b;
+        if (tr.J) tr.J[to] = J;
+        if (tr.accepted) tr.accepted[to] = accepted;
+        if (tr.alpha_idx) tr.alpha_idx[to] = j;
+        if (tr.mu) tr.mu[to] = mu;
+        if (tr.delta) tr.delta[to] = delta;
+        if (tr.qp_iter) tr.qp_iter[to] = S.qp_iter;
+        if (tr.qp_backtrack) tr.qp_backtrack[to] = S.qp_backtrack;
+        if (tr.n_clamped) tr.n_clamped[to] = S.n_clamped;
+        if (tr.stopped_at) tr.stopped_at[to] = stopped_at;
+        iters = it + 1;
+        if (converged)
+            status = ILQR_CONVERGED;
+        if (stop || converged)
+            break;
+    }
+    const double* xf = XS(cur);
+    const double* uf = US(cur);
+    const double* kf = KF(gcur);
+    const double* Kf = KG(gcur);
+    for (int t = 0; t <= T; ++t)
+        for (int i = 0; i < UN; ++i)
+            xs_out[(b * (T + 1) + t) * UN + i] = xf[((int64_t)t * UN + i) * 64 + bl];
+    for (int t = 0; t < T; ++t) {
+        for (int j = 0; j < UM; ++j) {
+            us_out[(b * T + t) * UM + j] = uf[((int64_t)t * UM + j) * 64 + bl];
+            k_io[(b * T + t) * UM + j] = kf[((int64_t)t * UM + j) * 64 + bl];
+        }
+        for (int i = 0; i < UM * UN; ++i)
+            K_io[(b * T + t) * UM * UN + i] = Kf[((int64_t)t * UM * UN + i) * 64 + bl];
+    }
+    delta_io[b] = delta;
+    J_out[b] = J;
+    mu_out[b] = mu;
+    iters_out[b] = iters;
+    status_out[b] = status;
+#undef XS
+#undef US
+#undef KF
+#undef KG
+}
+
+#endif // ILQR_USER_M
+
 int ucheck(const ilqr_user_model* m)
 {
     if (!m)
         return ILQR_ERR_ARG;
-    if (m->n != UN || m->m != 1 || m->n_params != ILQR_USER_NP)
+    if (m->n != UN || m->m != UM || m->n_params != ILQR_USER_NP)
         return ILQR_ERR_UNSUPPORTED;
     if (m->T < 1 || !m->Q || !m->R || !m->lower || !m->upper || (ILQR_USER_NP > 0 && !m->params))
         return ILQR_ERR_ARG;
@@ -579,6 +1043,8 @@ int ilqr_user_dims(int32_t* n, int32_t* n_params)
         *n_params = ILQR_USER_NP;
     return ILQR_OK;
 }
+
+int ilqr_user_controls(void) { return UM; }
 
 size_t ilqr_user_workspace_bytes(const ilqr_user_model* model, int64_t B)
 {
@@ -606,8 +1072,9 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
     UParams P;
     for (int i = 0; i < UNP; ++i)
         P.p[i] = i < ILQR_USER_NP ? model->params[i] : 0.0;
-    UCost C;
     const double* Qt = model->Q_terminal ? model->Q_terminal : model->Q;
+#if ILQR_USER_M == 1
+    UCost C;
     for (int a = 0; a < UN; ++a) {
         for (int b = 0; b < UN; ++b) {
             C.Q[a * UN + b] = model->Q[a * UN + b];
@@ -623,6 +1090,23 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
     UBounds bd;
     bd.lo = model->lower[0];
     bd.hi = model->upper[0];
+#else
+    GCost C;
+    for (int a = 0; a < UN * UN; ++a) {
+        C.Q[a] = model->Q[a];
+        C.Qt[a] = Qt[a];
+    }
+    for (int a = 0; a < UM * UM; ++a)
+        C.R[a] = model->R[a];
+    for (int a = 0; a < UN; ++a)
+        C.xg[a] = model->x_goal ? model->x_goal[a] : 0.0;
+    GBounds bd;
+    for (int a = 0; a < UM; ++a) {
+        C.ug[a] = model->u_goal ? model->u_goal[a] : 0.0;
+        bd.lo[a] = model->lower[a];
+        bd.hi[a] = model->upper[a];
+    }
+#endif
     SolveOptsP O;
     O.max_iter = opts->max_iter;
     O.n_alpha = opts->n_alpha;
@@ -658,6 +1142,9 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
+#if ILQR_USER_M > 1
+#define k_user_solve k_user_solve_m
+#endif
     hipLaunchKernelGGL(k_user_solve, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
                        P, C, O, bd, (int)T, B, static_cast<double*>(workspace), x0, us_init, delta, k, K, xs, us, J, mu,
                        iters, status, tr);

@@ -1,4 +1,4 @@
-"""User-defined dynamics on the GPU path (single control, up to 8 states).
+"""User-defined dynamics on the GPU path (up to 8 states, 1 to 4 controls).
 
 The reference takes any Python object with f / f_x / f_u (``AutogradDynamics``,
 ``FiniteDifferenceDynamics``, ilqr/ilqr_dynamics.py:94-575).  Python callbacks cannot run inside a
@@ -19,6 +19,7 @@ from .ilqr_dynamics import Dynamics
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _TU = os.path.join(_HERE, "csrc", "ilqr_user_tu.hip")
 _DEPS = [_TU, os.path.join(_HERE, "csrc", "ilqr_device.hpp"), os.path.join(_HERE, "csrc", "ilqr_math.hpp"),
+         os.path.join(_HERE, "csrc", "ilqr_qp_dense.hpp"),
          os.path.join(os.path.dirname(_HERE), "include", "ilqr_user.h"),
          os.path.join(os.path.dirname(_HERE), "include", "ilqr_user_fd.h"),
          os.path.join(os.path.dirname(_HERE), "include", "ilqr_hip.h")]
@@ -53,15 +54,16 @@ class UserModel(object):
     def __init__(self, lib, T, params, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None):
         n, npar = C.c_int32(), C.c_int32()
         _hip.check(lib.ilqr_user_dims(C.byref(n), C.byref(npar)))
-        self.lib, self.n, self.m, self.T = lib, n.value, 1, int(T)
+        m = int(lib.ilqr_user_controls())
+        self.lib, self.n, self.m, self.T = lib, n.value, m, int(T)
         host = _hip._host
-        self.a = dict(params=host(params, (npar.value,)), Q=host(Q, (self.n, self.n)), R=host(R, (1, 1)),
+        self.a = dict(params=host(params, (npar.value,)), Q=host(Q, (self.n, self.n)), R=host(R, (m, m)),
                       Q_terminal=host(Q if Q_terminal is None else Q_terminal, (self.n, self.n)),
                       x_goal=host(np.zeros(self.n) if x_goal is None else x_goal, (self.n,)),
-                      u_goal=host(np.zeros(1) if u_goal is None else u_goal, (1,)),
-                      lower=host(lower, (1,)), upper=host(upper, (1,)))
+                      u_goal=host(np.zeros(m) if u_goal is None else u_goal, (m,)),
+                      lower=host(lower, (m,)), upper=host(upper, (m,)))
         c = UserModelC()
-        c.n, c.m, c.T, c.n_params = self.n, 1, int(T), npar.value
+        c.n, c.m, c.T, c.n_params = self.n, m, int(T), npar.value
         for k, v in self.a.items():
             setattr(c, k, v.ctypes.data_as(C.POINTER(C.c_double)))
         self.c = c
@@ -73,6 +75,7 @@ def load(name):
         raise _hip.IlqrHipError("%s is missing: build it with ilqr_amd.user_model.build_user_model(header, %r)"
                                 % (path, name))
     lib = C.CDLL(path)
+    lib.ilqr_user_controls.restype = C.c_int
     lib.ilqr_user_workspace_bytes.restype = C.c_size_t
     lib.ilqr_user_workspace_bytes.argtypes = [C.POINTER(UserModelC), C.c_int64]
     return lib
@@ -82,12 +85,12 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
     """ilqr_user_solve_batched on reference-layout device tensors (same dict as _hip.solve)."""
     import torch
     B, dev = x0.shape[0], x0.device
-    T, n = M.T, M.n
+    T, n, m = M.T, M.n, M.m
     f64 = torch.float64
     delta = torch.full((B,), 2.0, dtype=f64, device=dev) if delta is None else delta
-    k = torch.zeros((B, T, 1), dtype=f64, device=dev) if k is None else k
-    K = torch.zeros((B, T, 1, n), dtype=f64, device=dev) if K is None else K
-    res = dict(xs=torch.empty((B, T + 1, n), dtype=f64, device=dev), us=torch.empty((B, T, 1), dtype=f64, device=dev),
+    k = torch.zeros((B, T, m), dtype=f64, device=dev) if k is None else k
+    K = torch.zeros((B, T, m, n), dtype=f64, device=dev) if K is None else K
+    res = dict(xs=torch.empty((B, T + 1, n), dtype=f64, device=dev), us=torch.empty((B, T, m), dtype=f64, device=dev),
                J=torch.empty(B, dtype=f64, device=dev), mu=torch.ones(B, dtype=f64, device=dev) if mu is None else mu,
                iters=torch.empty(B, dtype=torch.int32, device=dev), status=torch.empty(B, dtype=torch.int32, device=dev))
     need = int(M.lib.ilqr_user_workspace_bytes(C.byref(M.c), C.c_int64(B)))
@@ -103,7 +106,7 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
             setattr(tr_c, name, t.data_ptr())
     p, req = _hip._ptr, _hip._req
     _hip.check(M.lib.ilqr_user_solve_batched(
-        C.byref(M.c), C.byref(O.c), C.c_int64(B), p(req(x0.reshape(B, n), f64)), p(req(us_init.reshape(B, T, 1), f64)),
+        C.byref(M.c), C.byref(O.c), C.c_int64(B), p(req(x0.reshape(B, n), f64)), p(req(us_init.reshape(B, T, m), f64)),
         p(req(delta, f64)), p(req(k, f64)), p(req(K, f64)), p(res["xs"]), p(res["us"]), p(res["J"]), p(res["mu"]),
         p(res["iters"]), p(res["status"]), C.byref(tr_c) if tr_c is not None else None, p(workspace),
         C.c_size_t(workspace.numel()), _hip._stream()))
@@ -115,7 +118,8 @@ class UserDynamics(Dynamics):
     """A ``Dynamics`` backed by a per-model device library.
 
     name: the library built by ``build_user_model(header, name)``; params: the model's parameter
-    vector p; max_control: |u| <= max_control (``lower_bound`` / ``upper_bound``, as CartPoleDynamics)."""
+    vector p; max_control: |u| <= max_control, a number or one per control (``lower_bound`` /
+    ``upper_bound``, as CartPoleDynamics)."""
 
     device_model = "user"
 
@@ -124,10 +128,10 @@ class UserDynamics(Dynamics):
         self.lib = load(name)
         n, npar = C.c_int32(), C.c_int32()
         _hip.check(self.lib.ilqr_user_dims(C.byref(n), C.byref(npar)))
-        self._n = n.value
+        self._n, self._m = n.value, int(self.lib.ilqr_user_controls())
         self.params = np.asarray(params, dtype=np.float64).reshape(npar.value)
-        self.upper_bound = np.array([float(max_control)])
-        self.lower_bound = np.array([-float(max_control)])
+        self.upper_bound = np.broadcast_to(np.asarray(max_control, dtype=np.float64), (self._m,)).copy()
+        self.lower_bound = -self.upper_bound
 
     @property
     def state_dimension(self):
@@ -135,7 +139,7 @@ class UserDynamics(Dynamics):
 
     @property
     def control_dimension(self):
-        return 1
+        return self._m
 
     @property
     def has_hessians(self):

@@ -1,4 +1,4 @@
-/* C ABI of a per-model library for USER-DEFINED dynamics (single control, up to 8 states).
+/* C ABI of a per-model library for USER-DEFINED dynamics (up to 8 states, 1 to 4 controls).
  *
  * The reference accepts any Python object with f / f_x / f_u (AutogradDynamics,
  * FiniteDifferenceDynamics: ilqr/ilqr_dynamics.py:94-575) and calls it once per time step.
@@ -11,8 +11,11 @@
  *                                double* fx, double* fu);   (fx: [N][N] row-major, fu: [N])
  *
  * (or, instead of ilqr_user_jac,  #define ILQR_USER_FD : forward-difference Jacobian as the
- * reference's FiniteDifferenceDynamics, see ilqr_user_fd.h)
- * that may use ilqr_sincos(x, &s, &c), ilqr_atan2(y, x), ilqr_sqrt(x) and plain arithmetic;
+ * reference's FiniteDifferenceDynamics, see ilqr_user_fd.h).  With  #define ILQR_USER_M <2..4>
+ * the model has that many controls and both functions take  const double* u  (fu: [N][M]
+ * row-major); such models run on a general per-lane path (dense boxQP, serial line search).
+ * The functions
+ * may use ilqr_sincos(x, &s, &c), ilqr_atan2(y, x), ilqr_sqrt(x) and plain arithmetic;
  * ilqr_amd/csrc/ilqr_user_tu.hip is compiled around it into one shared library per model
  * (ilqr_amd.user_model.build_user_model does that with hipcc).  That library exports the
  * functions below; everything else (options, trace, array layouts, per-problem status)
@@ -31,16 +34,17 @@ extern "C" {
 
 /* Model parameters + QRCost (ilqr/ilqr_cost.py:490-530) + control bounds; HOST pointers. */
 typedef struct ilqr_user_model {
-    int32_t n, m, T;    /* n must equal the library's ILQR_USER_N, m must be 1 */
+    int32_t n, m, T;    /* n must equal the library's ILQR_USER_N, m its ILQR_USER_M (1 if not defined) */
     int32_t n_params;   /* must equal ILQR_USER_NP */
     const double* params;             /* [n_params] */
-    const double *Q, *R, *Q_terminal; /* [n*n], [1], [n*n] (Q_terminal NULL = Q) */
-    const double *x_goal, *u_goal;    /* [n], [1] (NULL = zeros) */
-    const double *lower, *upper;      /* [1] */
+    const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] (Q_terminal NULL = Q) */
+    const double *x_goal, *u_goal;    /* [n], [m] (NULL = zeros) */
+    const double *lower, *upper;      /* [m] */
 } ilqr_user_model;
 
-/* The dimensions the library was compiled for. */
+/* The dimensions the library was compiled for (states, parameters; controls). */
 int ilqr_user_dims(int32_t* n, int32_t* n_params);
+int ilqr_user_controls(void);
 
 /* iLQR.update_u (ilqr_core.py:241-399) for B problems; arguments as ilqr_solve_batched. */
 size_t ilqr_user_workspace_bytes(const ilqr_user_model* model, int64_t B);

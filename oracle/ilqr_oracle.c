@@ -49,8 +49,8 @@ enum { MODEL_CARTPOLE = 0, MODEL_LINEAR = 1, MODEL_SIGMOID = 2, MODEL_USER = 3 }
 
 /* A user-supplied model (single control): the same source the device library is built from,
  * compiled for the CPU (oracle/user_model_shim.c). */
-typedef void (*user_f_fn)(const double *p, const double *x, double u, double *out);
-typedef void (*user_jac_fn)(const double *p, const double *x, double u, double *fx, double *fu);
+typedef void (*user_f_fn)(const double *p, const double *x, const double *u, double *out);
+typedef void (*user_jac_fn)(const double *p, const double *x, const double *u, double *fx, double *fu);
 enum { COST_QR = 0, COST_PATHQR = 1 };
 enum { MATH_LIBM = 0, MATH_DET = 1 };
 
@@ -211,7 +211,7 @@ static void model_f(const oracle_model *P, const double *x, const double *u, dou
     }
     int n = P->n, m = P->m;
     if (P->model == MODEL_USER) {
-        P->user_f(P->user_p, x, u[0], out);
+        P->user_f(P->user_p, x, u, out);
         return;
     }
     if (P->model == MODEL_SIGMOID) {
@@ -248,7 +248,7 @@ static void model_fx_fu(const oracle_model *P, const double *x, const double *u,
         return;
     }
     if (P->model == MODEL_USER) {
-        P->user_jac(P->user_p, x, u[0], fx, fu);
+        P->user_jac(P->user_p, x, u, fx, fu);
         return;
     }
     if (P->model == MODEL_SIGMOID) {

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from oracle import c_oracle as co  # noqa: E402
-from test_user_model_cpu import cartpole_as_user, pendulum, pendulum_batch, pendulum_fd  # noqa: E402
+from test_user_model_cpu import (cartpole_as_user, pendulum, pendulum_batch, pendulum_fd, rotor,  # noqa: E402
+                                 rotor_batch)
 
 
 @pytest.fixture(scope="module")
@@ -87,6 +88,39 @@ def test_forward_difference_user_model_equals_oracle(hip):
     out = um.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0), trace=True)
     torch.cuda.synchronize()
     compare(out, ref, B)
+
+
+@pytest.mark.parametrize("B,T,max_iter", [(150, 50, 40), (65, 9, 6), (1, 30, 25)])
+def test_two_control_user_model_equals_oracle(hip, B, T, max_iter):
+    """m = 2: the general path of the per-model solver (dense boxQP with its index compaction,
+    dense Q-terms, serial line search) against the oracle's generic code on the same source."""
+    from ilqr_amd import user_model as um
+    Mo = rotor(T)
+    x0, us0 = rotor_batch(B, T, seed=70 + B)
+    ref = co.solve(Mo, co.Opts(max_iter=max_iter), x0, us0, nthreads=8)
+    M = um.UserModel(um.load("planar_rotor_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower,
+                     Mo.upper)
+    assert (M.n, M.m) == (7, 2)
+    out = um.solve(M, hip.Opts(max_iter=max_iter), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    compare(out, ref, B)
+    if B >= 100:
+        assert (ref["trace"]["n_clamped"] > 0).any()
+
+
+def test_two_control_model_through_the_solver_api(hip):
+    from ilqr_amd import QRCost, iLQR
+    from ilqr_amd.user_model import UserDynamics
+    from test_user_model_cpu import ROTOR_PARAMS
+    T, B = 30, 11
+    Mo = rotor(T)
+    x0, us0 = rotor_batch(B, T, seed=91)
+    ref = co.solve(Mo, co.Opts(max_iter=20), x0, us0, nthreads=8)
+    dyn = UserDynamics("planar_rotor_user", ROTOR_PARAMS, max_control=3.0)
+    assert dyn.control_dimension == 2 and dyn.state_dimension == 7
+    s = iLQR(dyn, QRCost(Mo.Q, Mo.R, Q_terminal=Mo.Qt, x_goal=Mo.x_goal), T)
+    xs, us = s.update_u(x0, us0, n_iterations=20)
+    assert us.shape == (B, T, 2) and eq(xs, ref["xs"]) and eq(us, ref["us"]) and eq(s.K_, ref["K"])
 
 
 def test_user_model_through_the_solver_api(hip):

@@ -32,6 +32,26 @@ def pendulum_fd(T):
     return co.user_model(lib, Ma.user_params, T, Ma.Q, Ma.R, Ma.Qt, Ma.x_goal, None, Ma.lower, Ma.upper)
 
 
+ROTOR_PARAMS = [0.05, 9.81, 1.0, 4.0, 0.1]
+
+
+def rotor(T):
+    """The two-control model (tests/models/planar_rotor_user.h): fly to the origin, level, at rest."""
+    lib = co.build_user_model(os.path.join(MODELS, "planar_rotor_user.h"), "planar_rotor_user")
+    Q = np.diag([10.0, 10.0, 5.0, 5.0, 1.0, 1.0, 1.0])
+    R = np.array([[0.2, 0.05], [0.05, 0.2]])
+    xg = [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
+    return co.user_model(lib, ROTOR_PARAMS, T, Q, R, 50.0 * np.eye(7), xg, None, [-3.0, -3.0], [3.0, 3.0])
+
+
+def rotor_batch(B, T, seed=7):
+    r = np.random.RandomState(seed)
+    phi = r.uniform(-1.0, 1.0, B)
+    x0 = np.stack([r.uniform(-2, 2, B), r.uniform(-2, 2, B), np.sin(phi), np.cos(phi), r.uniform(-1, 1, B),
+                   r.uniform(-1, 1, B), r.uniform(-1, 1, B)], axis=1)
+    return x0, r.uniform(-1, 1, (B, T, 2))
+
+
 def pendulum_batch(B, T, seed=3):
     r = np.random.RandomState(seed)
     th, w = r.uniform(-np.pi, np.pi, B), r.uniform(-1, 1, B)
@@ -70,6 +90,28 @@ def test_pendulum_jacobian_matches_finite_differences_and_solve_descends():
     assert (out["J"] < J0).all() and (out["trace"]["n_clamped"] > 0).any()
 
 
+def test_two_control_model_jacobian_and_solve():
+    T, B = 40, 6
+    M = rotor(T)
+    assert (M.n, M.m) == (7, 2)
+    x0, us0 = rotor_batch(B, T)
+    f, fx, fu = co.dynamics(M, x0[0], us0[0, 0])
+    eps = 1e-6
+    for j in range(7):
+        d = np.zeros(7)
+        d[j] = eps
+        col = (co.dynamics(M, x0[0] + d, us0[0, 0])[0][0] - co.dynamics(M, x0[0] - d, us0[0, 0])[0][0]) / (2 * eps)
+        np.testing.assert_allclose(fx[0][:, j], col, atol=1e-7)
+    for j in range(2):
+        d = np.zeros(2)
+        d[j] = eps
+        col = (co.dynamics(M, x0[0], us0[0, 0] + d)[0][0] - co.dynamics(M, x0[0], us0[0, 0] - d)[0][0]) / (2 * eps)
+        np.testing.assert_allclose(fu[0][:, j], col, atol=1e-7)
+    J0 = co.rollout_cost(M, x0, us0)[1]
+    out = co.solve(M, co.Opts(max_iter=40), x0, us0)
+    assert (out["J"] < 0.5 * J0).all() and (out["trace"]["n_clamped"] > 0).any()
+
+
 def test_forward_difference_model_follows_approx_fprime():
     """ilqr/ilqr_dynamics.py:145-167: row m of f_x is approx_fprime(x, f(.)[m], x_eps), i.e.
     (f(x + eps e_k) - f(x)) / eps with eps = sqrt(machine epsilon); checked against that formula
@@ -103,11 +145,13 @@ def test_user_model_libraries_export_every_declared_symbol():
     header = open(os.path.join(root, "include", "ilqr_user.h")).read()
     body = header[header.index("#ifndef ILQR_USER_H"):]
     declared = set(re.findall(r"\b(ilqr_user_[a-z0-9_]+)\s*\(", body))
-    assert declared == {"ilqr_user_dims", "ilqr_user_workspace_bytes", "ilqr_user_solve_batched"}
-    for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4)), ("pendulum_fd_user", (3, 4))):
+    assert declared == {"ilqr_user_dims", "ilqr_user_controls", "ilqr_user_workspace_bytes", "ilqr_user_solve_batched"}
+    for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4)), ("pendulum_fd_user", (3, 4)),
+                       ("planar_rotor_user", (7, 5))):
         um.build_user_model(os.path.join(MODELS, name + ".h"), name)  # hipcc cross-compiles; no-op when up to date
         lib = C.CDLL(um.library_path(name))  # loading needs no GPU
         for sym in declared:
             assert hasattr(lib, sym), (name, sym)
         n, npar = C.c_int32(), C.c_int32()
         assert lib.ilqr_user_dims(C.byref(n), C.byref(npar)) == 0 and (n.value, npar.value) == dims
+        assert lib.ilqr_user_controls() == (2 if name == "planar_rotor_user" else 1)
