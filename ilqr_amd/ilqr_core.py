@@ -43,7 +43,8 @@ class iLQR(BaseTrajOptimizer):
         if getattr(sys_dynamics, "device_model", None) not in ("cartpole", "sigmoid32", "user"):
             raise NotImplementedError(
                 "iLQR on the GPU needs a dynamics model with a device implementation "
-                "(ilqr_amd.cartpole.CartPoleDynamics, ilqr_amd.synthetic.SigmoidLinearDynamics); %r evaluates through Python callbacks, which cannot "
+                "(ilqr_amd.cartpole.CartPoleDynamics, ilqr_amd.synthetic.SigmoidLinearDynamics, or a C model "
+                "source compiled with ilqr_amd.user_model); %r evaluates through Python callbacks, which cannot "
                 "run inside a kernel" % type(sys_dynamics).__name__)
         if not isinstance(cost_func, (QRCost, PathQRCost)):
             raise NotImplementedError("only QRCost and PathQRCost have a device implementation")

@@ -211,3 +211,28 @@ def test_workload_definitions_agree_with_the_checkers():
         assert np.array_equal(a, b)
     for a, b in zip(bench.make_batch(9, 0), co.cartpole_batch(9)):
         assert np.array_equal(a, b)
+
+
+def test_finite_difference_dynamics_mirror():
+    """ilqr/ilqr_dynamics.py:93-167 on the host: forward differences with sqrt(eps) increments, the
+    u_eps quirk (:113), and the solver's refusal of Python-callback models."""
+    from ilqr_amd.ilqr_dynamics import AutogradDynamics, FiniteDifferenceDynamics
+    A = np.array([[1.0, 0.1], [-0.2, 0.9]])
+    Bm = np.array([[0.0], [0.5]])
+    f = lambda x, u, i: A.dot(x) + Bm.dot(u) + 0.01 * np.array([np.sin(x[0]), x[1] * u[0]])  # noqa: E731
+    d = FiniteDifferenceDynamics(f, 2, 1)
+    assert d.x_eps_ == np.sqrt(np.finfo(float).eps) == 2.0 ** -26
+    assert FiniteDifferenceDynamics(f, 2, 1, u_eps=1e-3).u_eps_ == 2.0 ** -26        # ignored without x_eps
+    assert FiniteDifferenceDynamics(f, 2, 1, x_eps=1e-4, u_eps=1e-3).u_eps_ == 1e-3
+    x, u = np.array([0.3, -0.7]), np.array([0.4])
+    fx, fu = d.f_x(x, u, 0), d.f_u(x, u, 0)
+    assert fx.shape == (2, 2) and fu.shape == (2, 1)
+    col0 = (f(x + np.array([d.x_eps_, 0.0]), u, 0) - f(x, u, 0)) / d.x_eps_
+    assert np.array_equal(fx[:, 0], col0)
+    np.testing.assert_allclose(fx, A + 0.01 * np.array([[np.cos(0.3), 0.0], [0.0, 0.4]]), atol=1e-6)
+    np.testing.assert_allclose(fu, Bm + 0.01 * np.array([[0.0], [-0.7]]), atol=1e-6)
+    assert d.f_xx(x, u, 0).shape == (2, 2, 2) and d.has_hessians
+    with pytest.raises(NotImplementedError):
+        iLQR(d, QRCost(np.eye(2), np.eye(1)), 5)
+    with pytest.raises(NotImplementedError):
+        AutogradDynamics(None, None, None)
