@@ -58,10 +58,20 @@ struct UParams {
 __host__ __device__ inline int64_t utile_rows(int64_t T) { return 2 * ((T + 1) * UN + T * UM + T * UM + T * UM * UN); }
 
 #if ILQR_USER_M == 1
-struct UCost { // QRCost, ilqr/ilqr_cost.py:490-530, m = 1
+struct UCost { // QRCost (ilqr/ilqr_cost.py:490-530) or PathQRCost (:635-770), m = 1
     double Q[UN * UN], Qt[UN * UN], QQ[UN * UN], QQt[UN * UN];
     double R, RR, xg[UN], ug;
+    const double *x_path, *u_path; // PathQRCost: device arrays [T+1][n], [T]; goals by time step, value without 1/2
+    int path;
 };
+// goal of time step t (wave-uniform loads in the path mode)
+__device__ __forceinline__ void ugoal_x(const UCost& C, int t, double (&xg)[UN])
+{
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+        xg[i] = C.path ? C.x_path[(int64_t)t * UN + i] : C.xg[i];
+}
+__device__ __forceinline__ double ugoal_u(const UCost& C, int t) { return C.path ? C.u_path[t] : C.ug; }
 struct UBounds {
     double lo, hi;
 };
@@ -93,31 +103,40 @@ __device__ __forceinline__ double uquad(const double (&v)[UN], const double* M)
     }
     return tot;
 }
-__device__ __forceinline__ double ucost_l(const UCost& C, const double (&x)[UN], double u)
+__device__ __forceinline__ double ucost_l(const UCost& C, const double (&x)[UN], double u, int t)
 {
-    double xd[UN];
+    double xd[UN], xg[UN];
+    ugoal_x(C, t, xg);
 #pragma unroll
     for (int i = 0; i < UN; ++i)
-        xd[i] = x[i] - C.xg[i];
-    double sx = uquad(xd, C.Q) * 0.5;
-    double ud = u - C.ug;
-    double su = ((ud * C.R) * ud) * 0.5;
+        xd[i] = x[i] - xg[i];
+    double sx = uquad(xd, C.Q);
+    double ud = u - ugoal_u(C, t);
+    double su = (ud * C.R) * ud;
+    if (!C.path) { // QRCost.l carries the 1/2 (ilqr_cost.py:547-552), PathQRCost.l does not (:695-701)
+        sx = sx * 0.5;
+        su = su * 0.5;
+    }
     return sx + su;
 }
-__device__ __forceinline__ double ucost_lT(const UCost& C, const double (&x)[UN])
+__device__ __forceinline__ double ucost_lT(const UCost& C, const double (&x)[UN], int T)
 {
-    double xd[UN];
+    double xd[UN], xg[UN];
+    ugoal_x(C, T, xg);
 #pragma unroll
     for (int i = 0; i < UN; ++i)
-        xd[i] = x[i] - C.xg[i];
-    return uquad(xd, C.Qt) * 0.5;
+        xd[i] = x[i] - xg[i];
+    double sx = uquad(xd, C.Qt);
+    return C.path ? sx : sx * 0.5;
 }
-__device__ __forceinline__ void ucost_lx(const double* QQ, const UCost& C, const double (&x)[UN], double (&out)[UN])
+__device__ __forceinline__ void ucost_lx(const double* QQ, const UCost& C, const double (&x)[UN], int t,
+                                         double (&out)[UN])
 {
-    double xd[UN];
+    double xd[UN], xg[UN];
+    ugoal_x(C, t, xg);
 #pragma unroll
     for (int i = 0; i < UN; ++i)
-        xd[i] = x[i] - C.xg[i];
+        xd[i] = x[i] - xg[i];
 #pragma unroll
     for (int j = 0; j < UN; ++j) {
         double acc = xd[0] * QQ[j];
@@ -136,13 +155,13 @@ struct UAcc {
 
 // One step of _backward_pass (ilqr_core.py:127-176) with the dense _compute_Q_terms (:179-228).
 __device__ __forceinline__ int ubw_step(const UParams& P, const UCost& C, const QPOptsP& QO, const double* tab,
-                                        const double (&x)[UN], double u, double mu, double lower, double upper,
+                                        const double (&x)[UN], double u, int t, double mu, double lower, double upper,
                                         UAcc& S, double& k_out, double (&K_out)[UN])
 {
     double fx[UN * UN], fu[UN], lx[UN];
     ilqr_user_jac(P.p, x, u, fx, fu);
-    ucost_lx(C.QQ, C, x, lx);
-    double lu = (u - C.ug) * C.RR;
+    ucost_lx(C.QQ, C, x, t, lx);
+    double lu = (u - ugoal_u(C, t)) * C.RR;
     const double* Vx = S.Vx;
     const double* Vxx = S.Vxx;
     double Qx[UN], Qxx[UN * UN], Qux[UN], M1[UN * UN], M2[UN];
@@ -257,7 +276,7 @@ __device__ int ubackward(const UParams& P, const UCost& C, const QPOptsP& QO, co
 {
     double xT[UN];
     uload(xs, ld, (int64_t)T * UN, b, xT);
-    ucost_lx(C.QQt, C, xT, S.Vx);
+    ucost_lx(C.QQt, C, xT, T, S.Vx);
 #pragma unroll
     for (int i = 0; i < UN * UN; ++i)
         S.Vxx[i] = C.QQt[i];
@@ -275,7 +294,7 @@ __device__ int ubackward(const UParams& P, const UCost& C, const QPOptsP& QO, co
             double x[UN], kt, Kt[UN];
             uload(xs, ld, (int64_t)i * UN, b, x);
             double u = us[(int64_t)i * ld + b];
-            int r = ubw_step(P, C, QO, tab, x, u, mu, bd.lo, bd.hi, S, kt, Kt);
+            int r = ubw_step(P, C, QO, tab, x, u, i, mu, bd.lo, bd.hi, S, kt, Kt);
             if (r == BW_OK) {
                 kk = kt;
 #pragma unroll
@@ -320,7 +339,7 @@ __device__ double uforward(const UParams& P, const UCost& C, int T, int64_t ld, 
             ustore(xs_new, ld, (int64_t)t * UN, b, xn);
             us_new[(int64_t)t * ld + b] = un;
         }
-        J = J + ucost_l(C, xn, un);
+        J = J + ucost_l(C, xn, un, t);
         ilqr_user_f(P.p, xn, un, xt);
 #pragma unroll
         for (int a = 0; a < UN; ++a)
@@ -328,7 +347,7 @@ __device__ double uforward(const UParams& P, const UCost& C, int T, int64_t ld, 
     }
     if (xs_new != nullptr)
         ustore(xs_new, ld, (int64_t)T * UN, b, xn);
-    return J + ucost_lT(C, xn);
+    return J + ucost_lT(C, xn, T);
 }
 
 // Workspace of one wavefront's 64 problems: rows of 64 doubles (lane = problem), two copies of
@@ -570,9 +589,13 @@ __global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C, SolveOpts
 // dense boxQP (boxqp_dense), and the serial first-hit line search.  Written for generality, not
 // speed: the per-problem matrices of the larger sizes live partly in scratch memory.
 
-struct GCost { // QRCost, ilqr/ilqr_cost.py:490-530
+struct GCost { // QRCost (ilqr/ilqr_cost.py:490-530) or PathQRCost (:635-770)
     double Q[UN * UN], Qt[UN * UN], R[UM * UM], xg[UN], ug[UM];
+    const double *x_path, *u_path; // PathQRCost: device arrays [T+1][n], [T][m]
+    int path;
 };
+__device__ __forceinline__ const double* ggoal_x(const GCost& C, int t) { return C.path ? C.x_path + (int64_t)t * UN : C.xg; }
+__device__ __forceinline__ const double* ggoal_u(const GCost& C, int t) { return C.path ? C.u_path + (int64_t)t * UM : C.ug; }
 struct GBounds {
     double lo[UM], hi[UM];
 };
@@ -593,26 +616,33 @@ __device__ __forceinline__ void gstore(double* base, int64_t row0, int64_t b, co
 }
 
 // QRCost.l, ilqr_cost.py:532-553 (the value carries the 1/2 its gradients lack)
-__device__ inline double gcost_l(const GCost& C, const double* x, const double* u, bool terminal)
+__device__ inline double gcost_l(const GCost& C, const double* x, const double* u, int t, bool terminal)
 {
     double xd[UN], ud[UM];
+    const double* xg = ggoal_x(C, t);
     for (int a = 0; a < UN; ++a)
-        xd[a] = x[a] - C.xg[a];
-    double sx = qpg_quad(UN, xd, terminal ? C.Qt : C.Q) * 0.5;
+        xd[a] = x[a] - xg[a];
+    double sx = qpg_quad(UN, xd, terminal ? C.Qt : C.Q);
+    if (!C.path) // PathQRCost.l has no 1/2 (:695-701)
+        sx = sx * 0.5;
     if (terminal)
         return sx;
+    const double* ug = ggoal_u(C, t);
     for (int a = 0; a < UM; ++a)
-        ud[a] = u[a] - C.ug[a];
-    double su = qpg_quad(UM, ud, C.R) * 0.5;
+        ud[a] = u[a] - ug[a];
+    double su = qpg_quad(UM, ud, C.R);
+    if (!C.path)
+        su = su * 0.5;
     return sx + su;
 }
 // l_x = x_diff^T (Q + Q^T), ilqr_cost.py:555-569
-__device__ inline void gcost_lx(const GCost& C, const double* x, bool terminal, double* out)
+__device__ inline void gcost_lx(const GCost& C, const double* x, int t, bool terminal, double* out)
 {
     const double* Qm = terminal ? C.Qt : C.Q;
+    const double* xg = ggoal_x(C, t);
     double xd[UN];
     for (int a = 0; a < UN; ++a)
-        xd[a] = x[a] - C.xg[a];
+        xd[a] = x[a] - xg[a];
     for (int j = 0; j < UN; ++j) {
         double acc = xd[0] * (Qm[j] + Qm[j * UN]);
         for (int a = 1; a < UN; ++a)
@@ -629,7 +659,7 @@ struct GAcc {
 
 // One step of _backward_pass (ilqr_core.py:127-176) with _compute_Q_terms (:179-228).
 __device__ int gbw_step(const UParams& P, const GCost& C, const QPOptsP& QO, const GBounds& bd, const double* x,
-                        const double* u, double mu, GAcc& S, double* ki, double* Ki)
+                        const double* u, int t, double mu, GAcc& S, double* ki, double* Ki)
 {
     constexpr int n = UN, m = UM;
     double fx[n * n], fu[n * m], lx[n], lu[m];
@@ -637,11 +667,12 @@ __device__ int gbw_step(const UParams& P, const GCost& C, const QPOptsP& QO, con
     const double* Vx = S.Vx;
     const double* Vxx = S.Vxx;
     ilqr_user_jac(P.p, x, u, fx, fu);
-    gcost_lx(C, x, false, lx);
+    gcost_lx(C, x, t, false, lx);
     {   // l_u = u_diff^T (R + R^T), ilqr_cost.py:571-587
         double ud[m];
+        const double* ug = ggoal_u(C, t);
         for (int a = 0; a < m; ++a)
-            ud[a] = u[a] - C.ug[a];
+            ud[a] = u[a] - ug[a];
         for (int j = 0; j < m; ++j) {
             double acc = ud[0] * (C.R[j] + C.R[j * m]);
             for (int a = 1; a < m; ++a)
@@ -791,7 +822,7 @@ __device__ int gbackward(const UParams& P, const GCost& C, const QPOptsP& QO, co
 {
     double xT[UN];
     gload<UN>(xs, (int64_t)T * UN, b, xT);
-    gcost_lx(C, xT, true, S.Vx);
+    gcost_lx(C, xT, T, true, S.Vx);
     for (int a = 0; a < UN; ++a)
         for (int c = 0; c < UN; ++c)
             S.Vxx[a * UN + c] = C.Qt[a * UN + c] + C.Qt[c * UN + a];
@@ -810,7 +841,7 @@ __device__ int gbackward(const UParams& P, const GCost& C, const QPOptsP& QO, co
             double x[UN], u[UM], kt[UM], Kt[UM * UN];
             gload<UN>(xs, (int64_t)i * UN, b, x);
             gload<UM>(us, (int64_t)i * UM, b, u);
-            int r = gbw_step(P, C, QO, bd, x, u, mu, S, kt, Kt);
+            int r = gbw_step(P, C, QO, bd, x, u, i, mu, S, kt, Kt);
             if (r == BW_OK) {
                 for (int a = 0; a < UM; ++a)
                     ki[a] = kt[a];
@@ -857,14 +888,14 @@ __device__ double gforward(const UParams& P, const GCost& C, int T, int64_t b, c
             gstore<UN>(xs_new, (int64_t)t * UN, b, xn);
             gstore<UM>(us_new, (int64_t)t * UM, b, un);
         }
-        J = J + gcost_l(C, xn, un, false);
+        J = J + gcost_l(C, xn, un, t, false);
         ilqr_user_f(P.p, xn, un, xt);
         for (int a = 0; a < UN; ++a)
             xn[a] = xt[a];
     }
     if (xs_new != nullptr)
         gstore<UN>(xs_new, (int64_t)T * UN, b, xn);
-    return J + gcost_l(C, xn, nullptr, true);
+    return J + gcost_l(C, xn, nullptr, T, true);
 }
 
 struct UWork {
@@ -1026,6 +1057,10 @@ int ucheck(const ilqr_user_model* m)
         return ILQR_ERR_UNSUPPORTED;
     if (m->T < 1 || !m->Q || !m->R || !m->lower || !m->upper || (ILQR_USER_NP > 0 && !m->params))
         return ILQR_ERR_ARG;
+    if (m->cost_kind != ILQR_COST_QR && m->cost_kind != ILQR_COST_PATH_QR)
+        return ILQR_ERR_UNSUPPORTED;
+    if (m->cost_kind == ILQR_COST_PATH_QR && (!m->x_goal || !m->u_goal))
+        return ILQR_ERR_ARG; // the paths are required (device arrays)
     return ILQR_OK;
 }
 
@@ -1073,6 +1108,7 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
     for (int i = 0; i < UNP; ++i)
         P.p[i] = i < ILQR_USER_NP ? model->params[i] : 0.0;
     const double* Qt = model->Q_terminal ? model->Q_terminal : model->Q;
+    const bool path = model->cost_kind == ILQR_COST_PATH_QR;
 #if ILQR_USER_M == 1
     UCost C;
     for (int a = 0; a < UN; ++a) {
@@ -1082,11 +1118,14 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
             C.QQ[a * UN + b] = model->Q[a * UN + b] + model->Q[b * UN + a];
             C.QQt[a * UN + b] = Qt[a * UN + b] + Qt[b * UN + a];
         }
-        C.xg[a] = model->x_goal ? model->x_goal[a] : 0.0;
+        C.xg[a] = (!path && model->x_goal) ? model->x_goal[a] : 0.0;
     }
     C.R = model->R[0];
     C.RR = model->R[0] + model->R[0];
-    C.ug = model->u_goal ? model->u_goal[0] : 0.0;
+    C.ug = (!path && model->u_goal) ? model->u_goal[0] : 0.0;
+    C.path = path ? 1 : 0;
+    C.x_path = path ? model->x_goal : nullptr;
+    C.u_path = path ? model->u_goal : nullptr;
     UBounds bd;
     bd.lo = model->lower[0];
     bd.hi = model->upper[0];
@@ -1099,10 +1138,13 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
     for (int a = 0; a < UM * UM; ++a)
         C.R[a] = model->R[a];
     for (int a = 0; a < UN; ++a)
-        C.xg[a] = model->x_goal ? model->x_goal[a] : 0.0;
+        C.xg[a] = (!path && model->x_goal) ? model->x_goal[a] : 0.0;
+    C.path = path ? 1 : 0;
+    C.x_path = path ? model->x_goal : nullptr;
+    C.u_path = path ? model->u_goal : nullptr;
     GBounds bd;
     for (int a = 0; a < UM; ++a) {
-        C.ug[a] = model->u_goal ? model->u_goal[a] : 0.0;
+        C.ug[a] = (!path && model->u_goal) ? model->u_goal[a] : 0.0;
         bd.lo[a] = model->lower[a];
         bd.hi[a] = model->upper[a];
     }

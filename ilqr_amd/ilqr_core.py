@@ -86,7 +86,9 @@ class iLQR(BaseTrajOptimizer):
         if d.device_model == "user":
             from . import user_model
             if isinstance(c, PathQRCost):
-                raise NotImplementedError("user models implement QRCost only")
+                x_path, u_path = c.device_paths(self._device())
+                return user_model.UserModel(d.lib, self.N, d.params, c.Q, c.R, c.Q_terminal, None, None,
+                                            self.lower_bound, self.upper_bound, x_path=x_path, u_path=u_path)
             return user_model.UserModel(d.lib, self.N, d.params, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal,
                                         self.lower_bound, self.upper_bound)
         if d.device_model == "sigmoid32":

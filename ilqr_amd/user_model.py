@@ -27,7 +27,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 
 class UserModelC(C.Structure):
-    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("n_params", C.c_int32)] + \
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("n_params", C.c_int32),
+                ("cost_kind", C.c_int32), ("pad_", C.c_int32)] + \
                [(k, C.POINTER(C.c_double)) for k in ("params", "Q", "R", "Q_terminal", "x_goal", "u_goal", "lower",
                                                      "upper")]
 
@@ -51,7 +52,10 @@ def build_user_model(header, name, force=False):
 class UserModel(object):
     """ctypes view of one per-model library + the host arrays of one problem family."""
 
-    def __init__(self, lib, T, params, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None):
+    def __init__(self, lib, T, params, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
+                 x_path=None, u_path=None):
+        """QRCost: x_goal [n], u_goal [m] (host).  PathQRCost: x_path [T+1, n], u_path [T, m] as device
+        tensors (time-indexed goals shared by the batch; the value then carries no 1/2)."""
         n, npar = C.c_int32(), C.c_int32()
         _hip.check(lib.ilqr_user_dims(C.byref(n), C.byref(npar)))
         m = int(lib.ilqr_user_controls())
@@ -66,6 +70,18 @@ class UserModel(object):
         c.n, c.m, c.T, c.n_params = self.n, m, int(T), npar.value
         for k, v in self.a.items():
             setattr(c, k, v.ctypes.data_as(C.POINTER(C.c_double)))
+        c.cost_kind = _hip.COST_QR
+        if x_path is not None or u_path is not None:
+            import torch
+            if x_path is None or u_path is None:
+                raise ValueError("PathQRCost needs both x_path and u_path")
+            self.x_path = _hip._req(x_path, torch.float64)
+            self.u_path = _hip._req(u_path, torch.float64)
+            if tuple(self.x_path.shape) != (int(T) + 1, self.n) or tuple(self.u_path.shape) != (int(T), m):
+                raise ValueError("x_path must be [%d, %d] and u_path [%d, %d]" % (int(T) + 1, self.n, int(T), m))
+            c.cost_kind = _hip.COST_PATH_QR
+            c.x_goal = C.cast(C.c_void_p(self.x_path.data_ptr()), C.POINTER(C.c_double))
+            c.u_goal = C.cast(C.c_void_p(self.u_path.data_ptr()), C.POINTER(C.c_double))
         self.c = c
 
 

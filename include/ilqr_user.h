@@ -36,6 +36,9 @@ extern "C" {
 typedef struct ilqr_user_model {
     int32_t n, m, T;    /* n must equal the library's ILQR_USER_N, m its ILQR_USER_M (1 if not defined) */
     int32_t n_params;   /* must equal ILQR_USER_NP */
+    int32_t cost_kind;  /* ILQR_COST_QR, or ILQR_COST_PATH_QR: x_goal / u_goal are then DEVICE arrays
+                           [T+1][n] / [T][m] (PathQRCost, ilqr/ilqr_cost.py:635-770), both required */
+    int32_t pad_;
     const double* params;             /* [n_params] */
     const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] (Q_terminal NULL = Q) */
     const double *x_goal, *u_goal;    /* [n], [m] (NULL = zeros) */

@@ -352,8 +352,10 @@ def build_user_model(header, name):
     return C.CDLL(out)
 
 
-def user_model(lib_user, params, T, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None):
+def user_model(lib_user, params, T, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
+               cost_kind=COST_QR):
+    """cost_kind=COST_PATHQR: x_goal [T+1, n], u_goal [T, m] are the paths of a PathQRCost."""
     n, m = lib_user.user_model_n(), lib_user.user_model_m()
     assert lib_user.user_model_np() == len(params)
-    return Model(MODEL_USER, n, m, T, COST_QR, MATH_DET, True, Q=Q, R=R, Q_terminal=Q_terminal, x_goal=x_goal,
+    return Model(MODEL_USER, n, m, T, cost_kind, MATH_DET, True, Q=Q, R=R, Q_terminal=Q_terminal, x_goal=x_goal,
                  u_goal=u_goal, lower=lower, upper=upper, user=lib_user, user_params=params)

@@ -123,6 +123,41 @@ def test_two_control_model_through_the_solver_api(hip):
     assert us.shape == (B, T, 2) and eq(xs, ref["xs"]) and eq(us, ref["us"]) and eq(s.K_, ref["K"])
 
 
+@pytest.mark.parametrize("which", ["pendulum", "rotor"])
+def test_user_models_track_a_path_with_pathqrcost(hip, which):
+    """PathQRCost (ilqr/ilqr_cost.py:635-770: goals by time step, value without the 1/2) on both
+    user-model paths, through the solver API, against the oracle."""
+    from ilqr_amd import PathQRCost, iLQR
+    from ilqr_amd.user_model import UserDynamics
+    from test_user_model_cpu import ROTOR_PARAMS
+    T, B = 40, 70
+    if which == "pendulum":
+        Mq = pendulum(T)
+        x0, us0 = pendulum_batch(B, T, seed=101)
+        th = np.linspace(0.0, 2.5, T + 1)
+        x_path = np.stack([np.sin(th), np.cos(th), np.full(T + 1, 2.5 / (T * 0.05))], axis=1)
+        u_path = 0.3 * np.cos(np.linspace(0, 3, T))[:, None]
+        dyn = UserDynamics("pendulum_user", Mq.user_params, max_control=2.0)
+    else:
+        Mq = rotor(T)
+        x0, us0 = rotor_batch(B, T, seed=102)
+        s_ = np.linspace(0.0, 1.0, T + 1)
+        x_path = np.stack([1.5 * s_, np.sin(3 * s_), np.zeros(T + 1), np.ones(T + 1), np.full(T + 1, 0.75),
+                           np.cos(3 * s_), np.zeros(T + 1)], axis=1)
+        u_path = 0.2 * np.stack([np.sin(np.linspace(0, 2, T)), np.cos(np.linspace(0, 2, T))], axis=1)
+        dyn = UserDynamics("planar_rotor_user", ROTOR_PARAMS, max_control=3.0)
+    Mo = co.user_model(Mq.user, Mq.user_params, T, Mq.Q, Mq.R, Mq.Qt, x_path, u_path, Mq.lower, Mq.upper,
+                       cost_kind=co.COST_PATHQR)
+    ref = co.solve(Mo, co.Opts(max_iter=30), x0, us0, nthreads=8)
+    s = iLQR(dyn, PathQRCost(Mq.Q, Mq.R, x_path, u_path, Q_terminal=Mq.Qt), T)
+    xs, us = s.update_u(x0, us0, n_iterations=30)
+    assert eq(xs, ref["xs"]) and eq(us, ref["us"]) and eq(s.K_, ref["K"])
+    assert np.array_equal(s.iterations_, ref["iters"])
+    # the cost really is the path cost: twice the QRCost value of the same deviation at step 0
+    c0 = co.user_model(Mq.user, Mq.user_params, T, Mq.Q, Mq.R, Mq.Qt, x_path[0], u_path[0], Mq.lower, Mq.upper)
+    assert ref["J"].min() > 0 and not eq(ref["J"], co.solve(c0, co.Opts(max_iter=30), x0, us0, nthreads=8)["J"])
+
+
 def test_user_model_through_the_solver_api(hip):
     from ilqr_amd import QRCost, iLQR
     from ilqr_amd.user_model import UserDynamics
