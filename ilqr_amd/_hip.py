@@ -34,7 +34,7 @@ class ModelC(C.Structure):
 
 class LargeModelC(C.Structure):
     _fields_ = [
-        ("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("pad_", C.c_int32),
+        ("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("cost_kind", C.c_int32),
         ("dt", C.c_double), ("sig_c", C.c_double),
         ("A", _vp), ("B", _vp), ("W", _vp), ("Q", _vp), ("R", _vp), ("Q_terminal", _vp),
         ("x_goal", _vp), ("u_goal", _vp), ("lower", _vp), ("upper", _vp),
@@ -367,7 +367,8 @@ class LargeModel:
     array is uploaded once and kept alive by this object."""
 
     def __init__(self, T, A, B, W, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
-                 dt=0.05, sig_c=2.0, device=None):
+                 dt=0.05, sig_c=2.0, device=None, x_path=None, u_path=None):
+        """x_path [T+1, 32], u_path [T, 8]: the goals of a PathQRCost instead of x_goal / u_goal."""
         import torch
         n, m = 32, 8
         self.n, self.m, self.T = n, m, int(T)
@@ -383,6 +384,13 @@ class LargeModel:
             lower=up(lower, (m,)), upper=up(upper, (m,)))
         c = LargeModelC()
         c.n, c.m, c.T, c.dt, c.sig_c = n, m, int(T), dt, sig_c
+        c.cost_kind = COST_QR
+        if x_path is not None or u_path is not None:
+            if x_path is None or u_path is None:
+                raise ValueError("PathQRCost needs both x_path and u_path")
+            self.t["x_goal"] = up(x_path, (int(T) + 1, n))
+            self.t["u_goal"] = up(u_path, (int(T), m))
+            c.cost_kind = COST_PATH_QR
         for name, t in self.t.items():
             setattr(c, name, t.data_ptr())
         self.c = c

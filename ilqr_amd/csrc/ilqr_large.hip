@@ -129,6 +129,7 @@ struct LargeP { // kernel arguments: the model, all device pointers
     const double *A, *B, *W, *Q, *R, *Qt, *xg, *ug, *lower, *upper;
     double dt, sig_c;
     int T;
+    int path; // PathQRCost: xg [T+1][n], ug [T][m] hold the goal of every time step, values carry no 1/2
 };
 
 struct LQPOpts {
@@ -588,6 +589,10 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
     xg[0][0] = load_v(M.xg, LN, 0, L);
     xg[1][0] = load_v(M.xg, LN, 1, L);
     ug[0][0] = load_v(M.ug, LM, 0, L);
+    if (P.path) { // the terminal goal
+        xg[0][0] = load_v(P.xg + (size_t)T * LN, LN, 0, L);
+        xg[1][0] = load_v(P.xg + (size_t)T * LN, LN, 1, L);
+    }
 
     // V_x, V_xx = terminal l_x, l_xx (:120-121)
     d4 Vx[2][1], Vxx[2][2];
@@ -652,6 +657,11 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         d4 Qu[1][1];
         {
             d4 ud[1][1], lu[1][1];
+            if (P.path) { // the goals of step i (ilqr_cost.py:682-701)
+                xg[0][0] = load_v(P.xg + (size_t)i * LN, LN, 0, L);
+                xg[1][0] = load_v(P.xg + (size_t)i * LN, LN, 1, L);
+                ug[0][0] = load_v(P.ug + (size_t)i * LM, LM, 0, L);
+            }
             ud[0][0] = uv[0][0] - ug[0][0];
             mm_tn<1, 1, 1, 2>(RR, ud, lu);
             mm_tn<2, 1, 1>(fu, Vx, Qu);
@@ -952,6 +962,11 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
         // l(x, u) = x_diff^T Q x_diff / 2 + u_diff^T R u_diff / 2   (ilqr_cost.py:532-553)
         {
             d4 xd[2][1], ud[1][1], ax[2][1], au[1][1], sx[1][1], su[1][1];
+            if (P.path) {
+                xg[0] = load_v(P.xg + (size_t)t * LN, LN, 0, L);
+                xg[1] = load_v(P.xg + (size_t)t * LN, LN, 1, L);
+                ug = load_v(P.ug + (size_t)t * LM, LM, 0, L);
+            }
             xd[0][0] = Xh[0][0] - xg[0];
             xd[1][0] = Xh[1][0] - xg[1];
             ud[0][0] = Uh[0][0] - ug;
@@ -962,7 +977,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (diag_lane[r])
-                    J = J + (sx[0][0][r] * 0.5 + su[0][0][r] * 0.5);
+                    J = J + (P.path ? sx[0][0][r] + su[0][0][r] : sx[0][0][r] * 0.5 + su[0][0][r] * 0.5);
         }
         // x+ = x + dt (A x + B u + c phi(W x))
         {
@@ -990,6 +1005,10 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
     }
     {
         d4 xd[2][1], ax[2][1], sx[1][1];
+        if (P.path) {
+            xg[0] = load_v(P.xg + (size_t)T * LN, LN, 0, L);
+            xg[1] = load_v(P.xg + (size_t)T * LN, LN, 1, L);
+        }
         xd[0][0] = Xh[0][0] - xg[0];
         xd[1][0] = Xh[1][0] - xg[1];
         mm_tn<2, 2, 1>(Qtn, xd, ax);
@@ -997,7 +1016,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (diag_lane[r]) {
-                J = J + sx[0][0][r] * 0.5;
+                J = J + (P.path ? sx[0][0][r] : sx[0][0][r] * 0.5);
                 S.J[L.c] = J;
             }
     }
@@ -1244,6 +1263,8 @@ int large_check(const ilqr_large_model* m)
     if (m->T < 1 || !m->A || !m->B || !m->W || !m->Q || !m->R || !m->Q_terminal || !m->x_goal || !m->u_goal ||
         !m->lower || !m->upper)
         return ILQR_ERR_ARG;
+    if (m->cost_kind != ILQR_COST_QR && m->cost_kind != ILQR_COST_PATH_QR)
+        return ILQR_ERR_UNSUPPORTED;
     return ILQR_OK;
 }
 
@@ -1263,6 +1284,7 @@ LargeP large_fill(const ilqr_large_model* m)
     P.dt = m->dt;
     P.sig_c = m->sig_c;
     P.T = m->T;
+    P.path = m->cost_kind == ILQR_COST_PATH_QR ? 1 : 0;
     return P;
 }
 

@@ -93,7 +93,9 @@ class iLQR(BaseTrajOptimizer):
                                         self.lower_bound, self.upper_bound)
         if d.device_model == "sigmoid32":
             if isinstance(c, PathQRCost):
-                raise NotImplementedError("the large-state path implements QRCost only")
+                return _hip.LargeModel(self.N, d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, None, None, self.lower_bound,
+                                       self.upper_bound, dt=d.tau, sig_c=d.sig_c, device=self._device(),
+                                       x_path=c.x_path, u_path=c.u_path)
             return _hip.LargeModel(self.N, d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal, self.lower_bound,
                                    self.upper_bound, dt=d.tau, sig_c=d.sig_c, device=self._device())
         kw = dict(dt=d.tau, mc=d.masscart, mp=d.masspole, l=d.length, g=d.gravity)

@@ -205,11 +205,12 @@ int ilqr_detmath(int64_t n, const double* a, const double* b, double* sin_a, dou
  * Every pointer of this struct is a DEVICE pointer (the matrices are read by the kernels). */
 typedef struct ilqr_large_model {
     int32_t n, m, T;  /* n must be 32, m must be 8 */
-    int32_t pad_;
+    int32_t cost_kind; /* ILQR_COST_QR, or ILQR_COST_PATH_QR: x_goal [T+1][n], u_goal [T][m] hold the goals
+                          of every time step (PathQRCost, ilqr/ilqr_cost.py:635-770) */
     double dt, sig_c; /* step and the gain c of the non-linearity */
     const double *A, *B, *W;          /* [n*n], [n*m], [n*n] row-major */
     const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] */
-    const double *x_goal, *u_goal;    /* [n], [m] */
+    const double *x_goal, *u_goal;    /* [n], [m] (or the paths, see cost_kind) */
     const double *lower, *upper;      /* [m] */
 } ilqr_large_model;
 

@@ -129,3 +129,31 @@ def test_large_model_through_the_solver_api(hip):
     np.testing.assert_allclose(dyn.f(x0[0], us0[0, 0], 0), f[0], rtol=1e-13, atol=1e-13)
     np.testing.assert_allclose(dyn.f_x(x0[0], us0[0, 0], 0), fx[0], rtol=1e-13, atol=1e-13)
     np.testing.assert_allclose(dyn.f_u(x0[0], us0[0, 0], 0), fu[0], rtol=1e-13, atol=1e-13)
+
+
+def test_large_model_tracks_a_path_with_pathqrcost(hip):
+    """PathQRCost (ilqr/ilqr_cost.py:635-770: goals by time step, value without the 1/2) on the
+    large-state path, through the solver API, against the oracle's generic code."""
+    from ilqr_amd import PathQRCost, iLQR
+    from ilqr_amd.synthetic import SigmoidLinearDynamics
+    T, B = 30, 10
+    Mq = co.synthetic_model(T=T)
+    r = np.random.RandomState(21)
+    x_path = 0.3 * np.cumsum(r.uniform(-0.1, 0.1, (T + 1, 32)), axis=0)
+    u_path = r.uniform(-0.2, 0.2, (T, 8))
+    Mo = co.Model(co.MODEL_SIGMOID, 32, 8, T, co.COST_PATHQR, co.MATH_DET, True, dt=Mq.dt, A=Mq.A, B=Mq.B, W=Mq.W,
+                  sig_c=Mq.sig_c, Q=Mq.Q, R=Mq.R, Q_terminal=Mq.Qt, x_goal=x_path, u_goal=u_path, lower=Mq.lower,
+                  upper=Mq.upper)
+    x0, us0 = co.synthetic_batch(B, T=T, seed_x=31, seed_u=32)
+    ref = co.solve(Mo, co.Opts(max_iter=15), x0, us0, nthreads=8)
+    dyn = SigmoidLinearDynamics(Mq.A, Mq.B, Mq.W, dt=Mq.dt, sig_c=Mq.sig_c, max_control=1.0)
+    s = iLQR(dyn, PathQRCost(Mq.Q, Mq.R, x_path, u_path, Q_terminal=Mq.Qt), T)
+    xs, us = s.update_u(x0, us0, n_iterations=15)
+    assert eq(xs, ref["xs"]) and eq(us, ref["us"]) and eq(s.K_, ref["K"])
+    assert np.array_equal(s.iterations_, ref["iters"]) and eq(s.J_, ref["J"])
+    # stage level: rollout cost and one backward sweep with the path goals
+    Mh = hip.LargeModel(T, Mq.A, Mq.B, Mq.W, Mq.Q, Mq.R, Mq.Qt, None, None, Mq.lower, Mq.upper, dt=Mq.dt,
+                        sig_c=Mq.sig_c, x_path=x_path, u_path=u_path)
+    xs_ref, J_ref = co.rollout_cost(Mo, x0, us0)
+    xs_g, J_g = hip.large_rollout_cost(Mh, dev(x0), dev(us0))
+    assert eq(xs_g.cpu().numpy(), xs_ref) and eq(J_g.cpu().numpy(), J_ref)
