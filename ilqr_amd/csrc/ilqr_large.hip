@@ -561,6 +561,7 @@ struct BwOut {
 
 // _backward_pass + _compute_Q_terms (ilqr_core.py:109-228) for one problem.
 // xs [T+1][32], us [T][8] -> k [T][8], K [T][8][32] (zeros where the sweep does not reach).
+template <bool PATH>
 __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMem& M, WaveMem& S, const double* xs,
                                const double* us, double mu, double* k, double* K, BwOut& out, int32_t* qp_result,
                                int32_t* free_mask)
@@ -589,7 +590,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
     xg[0][0] = load_v(M.xg, LN, 0, L);
     xg[1][0] = load_v(M.xg, LN, 1, L);
     ug[0][0] = load_v(M.ug, LM, 0, L);
-    if (P.path) { // the terminal goal
+    if (PATH) { // the terminal goal
         xg[0][0] = load_v(P.xg + (size_t)T * LN, LN, 0, L);
         xg[1][0] = load_v(P.xg + (size_t)T * LN, LN, 1, L);
     }
@@ -657,7 +658,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         d4 Qu[1][1];
         {
             d4 ud[1][1], lu[1][1];
-            if (P.path) { // the goals of step i (ilqr_cost.py:682-701)
+            if (PATH) { // the goals of step i (ilqr_cost.py:682-701)
                 xg[0][0] = load_v(P.xg + (size_t)i * LN, LN, 0, L);
                 xg[1][0] = load_v(P.xg + (size_t)i * LN, LN, 1, L);
                 ug[0][0] = load_v(P.ug + (size_t)i * LM, LM, 0, L);
@@ -902,7 +903,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 // (column c of every matrix belongs to alpha[c]); with ROLL the controls are us themselves
 // (_dynamics_rollout, :69-83).  J of column c ends up in S.J[c].  The trajectory of column
 // `store_col` (if >= 0) is written to xs_new / us_new.
-template <bool ROLL>
+template <bool ROLL, bool PATH>
 __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, const double* us, const double* k,
                               const double* K, const double* x0, double alpha_c, int store_col, double* xs_new,
                               double* us_new)
@@ -962,7 +963,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
         // l(x, u) = x_diff^T Q x_diff / 2 + u_diff^T R u_diff / 2   (ilqr_cost.py:532-553)
         {
             d4 xd[2][1], ud[1][1], ax[2][1], au[1][1], sx[1][1], su[1][1];
-            if (P.path) {
+            if (PATH) {
                 xg[0] = load_v(P.xg + (size_t)t * LN, LN, 0, L);
                 xg[1] = load_v(P.xg + (size_t)t * LN, LN, 1, L);
                 ug = load_v(P.ug + (size_t)t * LM, LM, 0, L);
@@ -977,7 +978,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (diag_lane[r])
-                    J = J + (P.path ? sx[0][0][r] + su[0][0][r] : sx[0][0][r] * 0.5 + su[0][0][r] * 0.5);
+                    J = J + (PATH ? sx[0][0][r] + su[0][0][r] : sx[0][0][r] * 0.5 + su[0][0][r] * 0.5);
         }
         // x+ = x + dt (A x + B u + c phi(W x))
         {
@@ -1005,7 +1006,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
     }
     {
         d4 xd[2][1], ax[2][1], sx[1][1];
-        if (P.path) {
+        if (PATH) {
             xg[0] = load_v(P.xg + (size_t)T * LN, LN, 0, L);
             xg[1] = load_v(P.xg + (size_t)T * LN, LN, 1, L);
         }
@@ -1016,7 +1017,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (diag_lane[r]) {
-                J = J + (P.path ? sx[0][0][r] : sx[0][0][r] * 0.5);
+                J = J + (PATH ? sx[0][0][r] : sx[0][0][r] * 0.5);
                 S.J[L.c] = J;
             }
     }
@@ -1025,6 +1026,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
 
 // ------------------------------------------------------------------ kernels
 
+template <bool PATH>
 __global__ __launch_bounds__(256) void k_large_rollout_cost(LargeP P, int64_t B, const double* x0, const double* us,
                                                             double* xs, double* J)
 {
@@ -1034,12 +1036,13 @@ __global__ __launch_bounds__(256) void k_large_rollout_cost(LargeP P, int64_t B,
     if (b >= B)
         return;
     WaveMem& S = M.wv[threadIdx.x >> 6];
-    large_forward<true>(P, S, nullptr, us + b * P.T * LM, nullptr, nullptr, x0 + b * LN, 0.0, 0,
+    large_forward<true, PATH>(P, S, nullptr, us + b * P.T * LM, nullptr, nullptr, x0 + b * LN, 0.0, 0,
                         xs + b * (P.T + 1) * LN, nullptr);
     if ((threadIdx.x & 63) == 0)
         J[b] = S.J[0];
 }
 
+template <bool PATH>
 __global__ __launch_bounds__(256) void k_large_backward(LargeP P, LQPOpts QO, int64_t B, const double* xs,
                                                         const double* us, const double* mu, double* k, double* K,
                                                         double* dJ, int32_t* info, int32_t* qp_result,
@@ -1052,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_large_backward(LargeP P, LQPOpts QO, in
         return;
     WaveMem& S = M.wv[threadIdx.x >> 6];
     BwOut o;
-    large_backward(P, QO, M, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
+    large_backward<PATH>(P, QO, M, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
                    K + b * P.T * LM * LN, o, qp_result ? qp_result + b * P.T : nullptr,
                    free_mask ? free_mask + b * P.T * LM : nullptr);
     if ((threadIdx.x & 63) == 0) {
@@ -1071,6 +1074,7 @@ struct LAlphas {
 };
 
 // J_new [B][n_alpha]; the trajectory of alpha[store_idx] (if >= 0) goes to xs_new / us_new.
+template <bool PATH>
 __global__ __launch_bounds__(256) void k_large_forward_ls(LargeP P, LAlphas al, int n_alpha, int store_idx, int64_t B,
                                                           const double* xs, const double* us, const double* k,
                                                           const double* K, double* J_new, double* xs_new,
@@ -1088,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_large_forward_ls(LargeP P, LAlphas al, 
         int j = pass * LA + L.c;
         double a = j < n_alpha ? al.a[j < 32 ? j : 0] : 0.0;
         int sc = (store_idx >= pass * LA && store_idx < (pass + 1) * LA) ? store_idx - pass * LA : -1;
-        large_forward<false>(P, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, k + b * P.T * LM,
+        large_forward<false, PATH>(P, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, k + b * P.T * LM,
                              K + b * P.T * LM * LN, xs + b * (P.T + 1) * LN, a, sc,
                              xs_new ? xs_new + b * (P.T + 1) * LN : nullptr, us_new ? us_new + b * P.T * LM : nullptr);
         if (lane < LA && pass * LA + lane < n_alpha)
@@ -1102,6 +1106,7 @@ struct LSolveBuf {
 };
 
 // iLQR.update_u (ilqr_core.py:241-399), one problem per wavefront.
+template <bool PATH>
 __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int64_t B, const double* x0,
                                                      const double* us_init, double* delta_io, double* k0, double* K0,
                                                      double* xs0, double* us0, LSolveBuf W, double* J_out,
@@ -1126,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int
     for (int i = lane; i < T * LM; i += 64)
         usb[0][i] = us_init[b * T * LM + i];
     wave_sync();
-    large_forward<true>(P, S, nullptr, usb[0], nullptr, nullptr, x0 + b * LN, 0.0, 0, xsb[0], nullptr);
+    large_forward<true, PATH>(P, S, nullptr, usb[0], nullptr, nullptr, x0 + b * LN, 0.0, 0, xsb[0], nullptr);
     double J = S.J[0];
     double mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
     double delta = delta_io[b];
@@ -1139,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int
         // backward pass with the LinAlgError retry loop (:287-299); when it gives up at mu_max
         // the line search below still runs on the previous gains and Delta_J terms, as in the reference
         for (;;) {
-            large_backward(P, O.qp, M, S, xsb[cur], usb[cur], mu, kb[gcur ^ 1], Kb[gcur ^ 1], bw, nullptr, nullptr);
+            large_backward<PATH>(P, O.qp, M, S, xsb[cur], usb[cur], mu, kb[gcur ^ 1], Kb[gcur ^ 1], bw, nullptr, nullptr);
             wave_sync();
             if (bw.rc == 0) {
                 gcur ^= 1;
@@ -1161,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int
             for (int pass = 0; pass * LA < O.n_alpha && !ended; ++pass) {
                 int jj = pass * LA + L.c;
                 double a = jj < O.n_alpha ? O.alphas[jj < 32 ? jj : 0] : 0.0;
-                large_forward<false>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], a, pass == 0 ? 0 : -1,
+                large_forward<false, PATH>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], a, pass == 0 ? 0 : -1,
                                      xsb[nxt], usb[nxt]);
                 int win = -1;
                 for (int c = 0; c < LA && pass * LA + c < O.n_alpha; ++c) {
@@ -1187,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int
                 if (accepted && !(pass == 0 && win == 0)) {
                     // the accepted candidate's states and controls (same arithmetic, same bits)
                     double aw = O.alphas[pass * LA + L.c < O.n_alpha ? pass * LA + L.c : 0];
-                    large_forward<false>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], aw, win, xsb[nxt],
+                    large_forward<false, PATH>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], aw, win, xsb[nxt],
                                          usb[nxt]);
                 }
             }
@@ -1323,8 +1328,13 @@ int ilqr_large_rollout_cost(const ilqr_large_model* model, int64_t B, const doub
         return rc;
     if (B < 1 || !x0 || !us || !xs || !J)
         return ILQR_ERR_ARG;
-    hipLaunchKernelGGL(k_large_rollout_cost, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), B, x0, us,
-                       xs, J);
+    if (model->cost_kind == ILQR_COST_PATH_QR) {
+        hipLaunchKernelGGL(k_large_rollout_cost<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), B, x0, us,
+                           xs, J);
+    } else {
+        hipLaunchKernelGGL(k_large_rollout_cost<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), B, x0, us,
+                           xs, J);
+    }
     return lrc(hipGetLastError());
 }
 
@@ -1341,8 +1351,13 @@ int ilqr_large_backward(const ilqr_large_model* model, const ilqr_opts* opts, in
         return rc;
     if (B < 1 || !xs || !us || !mu || !k || !K || !dJ || !info)
         return ILQR_ERR_ARG;
-    hipLaunchKernelGGL(k_large_backward, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), q, B, xs, us,
-                       mu, k, K, dJ, info, qp_result, free_mask);
+    if (model->cost_kind == ILQR_COST_PATH_QR) {
+        hipLaunchKernelGGL(k_large_backward<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), q, B, xs, us,
+                           mu, k, K, dJ, info, qp_result, free_mask);
+    } else {
+        hipLaunchKernelGGL(k_large_backward<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), q, B, xs, us,
+                           mu, k, K, dJ, info, qp_result, free_mask);
+    }
     return lrc(hipGetLastError());
 }
 
@@ -1360,8 +1375,13 @@ int ilqr_large_forward_ls(const ilqr_large_model* model, int64_t B, int32_t n_al
     LAlphas al;
     for (int i = 0; i < 32; ++i)
         al.a[i] = i < n_alpha ? alphas[i] : 0.0;
-    hipLaunchKernelGGL(k_large_forward_ls, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), al,
-                       (int)n_alpha, (int)store_idx, B, xs, us, k, K, J_new, xs_new, us_new);
+    if (model->cost_kind == ILQR_COST_PATH_QR) {
+        hipLaunchKernelGGL(k_large_forward_ls<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), al,
+                           (int)n_alpha, (int)store_idx, B, xs, us, k, K, J_new, xs_new, us_new);
+    } else {
+        hipLaunchKernelGGL(k_large_forward_ls<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), al,
+                           (int)n_alpha, (int)store_idx, B, xs, us, k, K, J_new, xs_new, us_new);
+    }
     return lrc(hipGetLastError());
 }
 
@@ -1432,8 +1452,13 @@ int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opt
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
-    hipLaunchKernelGGL(k_large_solve, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), O, B, x0, us_init,
-                       delta, k, K, xs, us, W, J, mu, iters, status, tr);
+    if (model->cost_kind == ILQR_COST_PATH_QR) {
+        hipLaunchKernelGGL(k_large_solve<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), O, B, x0, us_init,
+                           delta, k, K, xs, us, W, J, mu, iters, status, tr);
+    } else {
+        hipLaunchKernelGGL(k_large_solve<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), O, B, x0, us_init,
+                           delta, k, K, xs, us, W, J, mu, iters, status, tr);
+    }
     return lrc(hipGetLastError());
 }
 
