@@ -85,7 +85,7 @@ def main_large(args):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    B, TL, n, m = (args.batch if args.batch != B_PER_GPU else 8192), 200, 32, 8
+    B, TL, n, m = (args.batch if args.batch is not None else 8192), 200, 32, 8
     wl = SyntheticWorkload(n=n, m=m, T=TL)
     M = wl.device_model(device=dev)
     x0_h, us_h = wl.batch(B, seed_x=5 + 1000 * rank, seed_u=6 + 1000 * rank)
@@ -171,7 +171,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="problems per GPU (default: %d cart-pole problems, 8192 large-state problems)" % B_PER_GPU)
     ap.add_argument("--cpu-sample", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -194,7 +195,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    B = args.batch
+    B = args.batch if args.batch is not None else B_PER_GPU
     Q, R, Qt, xg = cartpole_cost()
     M = _hip.Model(T, Q, R, Qt, xg, None, [-5.0], [5.0], dt=0.05)
     O = _hip.Opts()
