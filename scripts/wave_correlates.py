@@ -2,7 +2,8 @@
 the XCD it ran on) go with its lifetime in the solve kernel, over three runs of the benchmark batch."""
 import ctypes as C, os, sys
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ilqr_amd import _hip
 import bench
 B=16384
