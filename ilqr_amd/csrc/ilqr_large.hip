@@ -184,28 +184,49 @@ struct QPR {
     bool linalg;
 };
 
+// The free set as a scalar bit mask: every lane of the wave holds the same problem, so the mask is
+// wave-uniform and a test of one of its bits is a scalar branch (clamped rows and columns are then
+// skipped instead of computed and discarded; what is skipped are exact zeros and the unused pivots).
+__device__ __forceinline__ unsigned lr_mask(const bool (&fr)[LM])
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < LM; ++i)
+        m |= fr[i] ? (1u << i) : 0u;
+    return __builtin_amdgcn_readfirstlane(m);
+}
+
 // Lower Cholesky factor of H restricted to the free set; returns true if a free pivot is not > 0.
 __device__ __forceinline__ bool lr_chol(const double* H, const bool (&fr)[LM], double (&Lf)[LM][LM], double (&rd)[LM])
 {
+    const unsigned fm = lr_mask(fr);
     bool fail = false;
 #pragma unroll
     for (int j = 0; j < LM; ++j) {
+        if (!(fm & (1u << j))) { // clamped column: unit pivot, zero column
+            Lf[j][j] = 1.0;
+            rd[j] = 1.0;
+#pragma unroll
+            for (int i = j + 1; i < LM; ++i)
+                Lf[i][j] = 0.0;
+            continue;
+        }
         double s = H[j * LM + j];
 #pragma unroll
         for (int k = 0; k < j; ++k)
             s = fma(-Lf[j][k], Lf[j][k], s);
-        fail = fail || (fr[j] && !(s > 0.0));
+        fail = fail || !(s > 0.0);
         double d = sqrt(s);
         double r = 1.0 / d;
-        Lf[j][j] = fr[j] ? d : 1.0;
-        rd[j] = fr[j] ? r : 1.0;
+        Lf[j][j] = d;
+        rd[j] = r;
 #pragma unroll
         for (int i = j + 1; i < LM; ++i) {
             double t = H[i * LM + j];
 #pragma unroll
             for (int k = 0; k < j; ++k)
                 t = fma(-Lf[i][k], Lf[j][k], t);
-            Lf[i][j] = (fr[j] && fr[i]) ? t * r : 0.0;
+            Lf[i][j] = fr[i] ? t * r : 0.0;
         }
     }
     return fail;
