@@ -208,38 +208,55 @@ class iLQR(BaseTrajOptimizer):
         xs = torch.empty((B, self.N + 1, x0_d.shape[1]), dtype=torch.float64, device=dev)
         us = us_d.clone()
         J = torch.empty(B, dtype=torch.float64, device=dev)
-        active = torch.ones(B, dtype=torch.bool, device=dev)
         O = _hip.Opts(max_iter=1, mu_from_array=True, **kw)
-        first = True
-        for it in range(max_iter):
-            idx = torch.nonzero(active).flatten()
-            if idx.numel() == 0:
-                break
-            d_i, k_i, K_i, mu_i = delta[idx].contiguous(), k[idx].contiguous(), K[idx].contiguous(), mu[idx].contiguous()
-            res = self._solve(M, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
-                             trace=True)
-            acc = res["trace"]["accepted"][0] == 1
-            conv = res["status"] == _hip.STATUS_CONVERGED
-            stopped = res["status"] == _hip.STATUS_MU_MAX
-            delta[idx], k[idx], K[idx], mu[idx] = d_i, k_i, K_i, mu_i
-            xs[idx], us[idx], J[idx] = res["xs"], res["us"], res["J"]
-            iters[idx] += 1
-            status[idx] = res["status"]
-            # the reference leaves the loop on mu >= mu_max BEFORE the callback (ilqr_core.py:337-345)
-            call = ~stopped
-            if bool(call.any()):
-                sel = idx[call]
+        active_h = np.ones(B, dtype=bool)  # host copy of the running set: one device read-back per iteration
+        ws = None
 
-                def view(t):
-                    t = t[0] if single else t
-                    return t if as_torch else t.cpu().numpy()
-                if single:
-                    on_iteration(it, view(xs[sel]), view(us[sel]), float(J[sel][0]), bool(acc[call][0]),
-                                 bool(conv[call][0]))
+        def view(t):
+            t = t[0] if single else t
+            return t if as_torch else t.cpu().numpy()
+
+        for it in range(max_iter):
+            if not active_h.any():
+                break
+            everyone = bool(active_h.all())
+            if everyone:
+                # nothing has finished yet: the solver works on the full arrays in place
+                res = self._solve(M, O, x0_d, us, delta=delta, k=k, K=K, mu=mu, trace=True, workspace=ws)
+                ws = res["workspace"]
+                xs, us, J = res["xs"], res["us"], res["J"]
+                iters += 1
+                status = res["status"]
+                idx = None
+            else:
+                idx = torch.tensor(np.nonzero(active_h)[0], device=dev)
+                d_i, k_i, K_i, mu_i = delta[idx].contiguous(), k[idx].contiguous(), K[idx].contiguous(), mu[idx].contiguous()
+                res = self._solve(M, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
+                                  trace=True)
+                delta[idx], k[idx], K[idx], mu[idx] = d_i, k_i, K_i, mu_i
+                xs[idx], us[idx], J[idx] = res["xs"], res["us"], res["J"]
+                iters[idx] += 1
+                status[idx] = res["status"]
+            flags = torch.stack([res["status"], res["trace"]["accepted"][0]]).cpu().numpy()
+            conv_h = flags[0] == _hip.STATUS_CONVERGED
+            stopped_h = flags[0] == _hip.STATUS_MU_MAX
+            acc_h = flags[1] == 1
+            # the reference leaves the loop on mu >= mu_max BEFORE the callback (ilqr_core.py:337-345)
+            call_h = ~stopped_h
+            if call_h.any():
+                if call_h.all():
+                    xs_c, us_c, J_c = res["xs"], res["us"], res["J"]
                 else:
-                    on_iteration(it, view(xs[sel]), view(us[sel]), view(J[sel]), view(acc[call]), view(conv[call]))
-            active[idx] = ~(conv | stopped)
-            first = False
+                    sel = torch.tensor(np.nonzero(call_h)[0], device=dev)
+                    xs_c, us_c, J_c = res["xs"][sel], res["us"][sel], res["J"][sel]
+                if single:
+                    on_iteration(it, view(xs_c), view(us_c), float(J_c[0]), bool(acc_h[call_h][0]), bool(conv_h[call_h][0]))
+                else:
+                    acc_c, conv_c = acc_h[call_h], conv_h[call_h]
+                    if as_torch:
+                        acc_c, conv_c = torch.tensor(acc_c, device=dev), torch.tensor(conv_c, device=dev)
+                    on_iteration(it, view(xs_c), view(us_c), view(J_c), acc_c, conv_c)
+            active_h[np.nonzero(active_h)[0]] = ~(conv_h | stopped_h)
         return xs, us, J, mu, iters, status
 
 
