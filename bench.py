@@ -212,7 +212,7 @@ def main():
     delta = torch.empty(B, dtype=torch.float64, device=dev)
     k = torch.empty((B, T, 1), dtype=torch.float64, device=dev)
     K = torch.empty((B, T, 1, 5), dtype=torch.float64, device=dev)
-    from ilqr_amd import sharding
+    from ilqr_amd import compaction, sharding
     sizes = [B] * world
 
     def step():
@@ -220,7 +220,12 @@ def main():
         delta.fill_(2.0)
         k.zero_()
         K.zero_()
-        res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws, out=out_buf)
+        if B >= compaction.COMPACT_MIN_BATCH:  # the product's policy for batches that fill the GPU
+            res = compaction.solve_compacting(_hip.solve, M, {}, O.max_iter, x0, us0, delta=delta, k=k, K=K)
+            for name in out_buf:
+                out_buf[name] = res[name]
+        else:
+            res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws, out=out_buf)
         if world > 1:  # the only exchange of the path: results to rank 0 over xGMI
             for name in ("J", "iters", "status", "xs", "us"):
                 sharding.gather_to_root(out_buf[name], sizes, dst=0)
@@ -289,8 +294,10 @@ def main():
                        "converged_fraction": float((status == 1).mean()), "mean_final_cost": float(J.mean())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_solve (whole update_u loop, one launch per step; its pack/unpack "
-                                   "transposes are inside the timed span)",
+                         "kernel": ("k_solve (whole update_u loop, one launch per step; its pack/unpack "
+                                    "transposes are inside the timed span)" if B < compaction.COMPACT_MIN_BATCH else
+                                    "k_solve in launches of %d iterations, finished problems dropped in between "
+                                    "(gathers and transposes inside the timed span)" % compaction.COMPACT_CHUNK),
                          "kernel_ms": step_ms_events,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = problem-iterations x %d B (derivative tensors streamed "

@@ -175,7 +175,12 @@ class iLQR(BaseTrajOptimizer):
                   mu_max=self.mu_max_ if self.mu_max_ else 0.0, delta0=self.delta_0_)
 
         if on_iteration is None:
-            res = self._solve(M, _hip.Opts(max_iter=n_interations, **kw), x0_d, us_d, delta=delta, k=k, K=K)
+            if isinstance(M, _hip.LargeModel):  # one problem per wavefront: a finished problem frees its wave
+                res = self._solve(M, _hip.Opts(max_iter=n_interations, **kw), x0_d, us_d, delta=delta, k=k, K=K)
+            else:  # lane per problem: very large batches drop their finished problems between chunks of iterations
+                from . import compaction
+                res = compaction.solve_auto(lambda M_, O_, *a, **b: self._solve(M_, O_, *a, **b), M, kw, n_interations,
+                                            x0_d, us_d, delta=delta, k=k, K=K)
             xs, us, J, mu = res["xs"], res["us"], res["J"], res["mu"]
             iters, status = res["iters"], res["status"]
         else:

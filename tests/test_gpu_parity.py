@@ -522,3 +522,27 @@ def test_dense_and_diagonal_cost_evaluators_agree(hip, monkeypatch):
     Mf = co.Model(co.MODEL_CARTPOLE, 5, 1, T, co.COST_QR, co.MATH_DET, True, Q=Qf, R=Mo.R, Q_terminal=Qtf,
                   x_goal=Mo.x_goal, u_goal=[0.3], lower=Mo.lower, upper=Mo.upper)
     _check_solve(hip, Mf, x0, us0, 30)
+
+
+@pytest.mark.parametrize("B,chunk", [(3000, 7), (130, 1), (64, 200)])
+def test_chunked_solve_with_compaction_equals_single_launch(hip, B, chunk):
+    """Launches of `chunk` iterations with the finished problems dropped in between give the single
+    launch's results, counts and per-iteration trace, bit for bit; a sample is checked against the
+    oracle as well."""
+    from ilqr_amd import compaction
+    Mo = co.cartpole_model()
+    M = hip_model(hip, Mo)
+    x0, us0 = co.cartpole_batch(B, seed_x=71, seed_u=72)
+    one = hip.solve(M, hip.Opts(max_iter=60), dev(x0), dev(us0), trace=True)
+    chunked = compaction.solve_compacting(hip.solve, M, {}, 60, dev(x0), dev(us0), chunk=chunk, trace=True)
+    torch.cuda.synchronize()
+    for key in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K"):
+        assert torch.equal(one[key], chunked[key]), key
+    it = one["iters"].cpu().numpy()
+    for key in one["trace"]:
+        a, b = one["trace"][key].cpu().numpy(), chunked["trace"][key].cpu().numpy()
+        for p in range(0, B, max(1, B // 40)):
+            assert eq(a[:it[p], p], b[:it[p], p]), (key, p)
+    ref = co.solve(Mo, co.Opts(max_iter=60), x0[:40], us0[:40], nthreads=8)
+    assert eq(chunked["xs"][:40].cpu().numpy(), ref["xs"]) and np.array_equal(it[:40], ref["iters"])
+    assert (it < 60).any() and (it == 60).any()
