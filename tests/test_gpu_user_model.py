@@ -202,3 +202,20 @@ def test_user_model_rejects_mismatched_dimensions(hip):
     M.c.n = 4
     with pytest.raises(hip.IlqrHipError):
         um.solve(M, hip.Opts(max_iter=2), dev(np.zeros((2, 3))), dev(np.zeros((2, 10, 1))))
+
+
+def test_user_model_chunked_solve_with_compaction(hip):
+    """The chunked solve (finished problems dropped between launches) with a per-model library
+    as the solver: same results as its single launch."""
+    from ilqr_amd import compaction, user_model as um
+    T, B = 40, 500
+    Mo = pendulum(T)
+    x0, us0 = pendulum_batch(B, T, seed=111)
+    M = um.UserModel(um.load("pendulum_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower, Mo.upper)
+    one = um.solve(M, hip.Opts(max_iter=50), dev(x0), dev(us0))
+    chunked = compaction.solve_compacting(um.solve, M, {}, 50, dev(x0), dev(us0), chunk=6)
+    torch.cuda.synchronize()
+    for key in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K"):
+        assert torch.equal(one[key], chunked[key]), key
+    it = one["iters"].cpu().numpy()
+    assert (it < 50).any() and it.max() > 6
