@@ -109,6 +109,27 @@ def test_batched_update_u_numpy_and_torch():
         iLQR(dyn, cost, 50).update_u(x0, us0[:, :49])
 
 
+def test_update_u_on_a_batch_that_fills_the_gpu_is_the_single_launch():
+    """From 49152 problems on update_u solves in chunks of iterations and drops the finished problems
+    in between: same results as the C entry point called once, and a sample equals the oracle."""
+    from ilqr_amd import _hip, compaction, iLQR
+    dyn, cost, Mo = example_problem(N=30)
+    B = compaction.COMPACT_MIN_BATCH
+    x0, us0 = co.cartpole_batch(B, T=30, seed_x=81, seed_u=82)
+    dx, du = torch.tensor(x0, device="cuda"), torch.tensor(us0, device="cuda")
+    s = iLQR(dyn, cost, 30)
+    xs, us = s.update_u(dx, du, n_iterations=80)
+    M = _hip.Model(30, cost.Q, cost.R, cost.Q_terminal, cost.x_goal, None, [-5.0], [5.0])
+    one = _hip.solve(M, _hip.Opts(max_iter=80), dx, du)
+    assert torch.equal(xs, one["xs"]) and torch.equal(us, one["us"]) and torch.equal(s.K_, one["K"])
+    assert torch.equal(s.iterations_, one["iters"]) and torch.equal(s.status_, one["status"])
+    it = one["iters"].cpu().numpy()
+    assert it.min() < compaction.COMPACT_CHUNK < it.max()
+    pick = np.linspace(0, B - 1, 24).astype(int)
+    ref = co.solve(Mo, co.Opts(max_iter=80), x0[pick], us0[pick], nthreads=8, trace=False)
+    assert eq(xs[pick].cpu().numpy(), ref["xs"]) and np.array_equal(it[pick], ref["iters"])
+
+
 def test_receding_horizon_closed_loop_against_reference_run(golden_dir):
     """RecedingHorizonController + plant as in examples/cartpole_example_mpc.py:66-79, against
     the run recorded from the reference's controller (which includes re-solves that hit a
