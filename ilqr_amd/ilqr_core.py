@@ -71,8 +71,9 @@ class iLQR(BaseTrajOptimizer):
         self.delta_ = self.delta_0_
 
         n, m = self.dynamics.state_dimension, self.dynamics.control_dimension
-        self.k_ = np.zeros((self.N, m))
-        self.K_ = np.zeros((self.N, m, n))
+        self._gains = {"k": np.zeros((self.N, m)), "K": np.zeros((self.N, m, n))}
+        self._gains_np = {}        # numpy views of device-resident gains, made on first access
+        self._gains_as_numpy = True
         # per-problem results of the last call (device-side bookkeeping the reference does not have)
         self.iterations_ = None
         self.status_ = None
@@ -105,6 +106,22 @@ class iLQR(BaseTrajOptimizer):
                               x_path=x_path, u_path=u_path, **kw)
         return _hip.Model(self.N, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal, self.lower_bound, self.upper_bound, **kw)
 
+    # k_, K_ (ilqr_core.py:64-65, :394-395): feed-forward and feedback gains of the last solve
+    def _gain(self, name):
+        v = self._gains[name]
+        if _is_torch(v) and self._gains_as_numpy:
+            if name not in self._gains_np:
+                self._gains_np[name] = v.cpu().numpy()
+            return self._gains_np[name]
+        return v
+
+    def _set_gain(self, name, value):
+        self._gains[name] = value
+        self._gains_np.pop(name, None)
+
+    k_ = property(lambda self: self._gain("k"), lambda self, v: self._set_gain("k", v))
+    K_ = property(lambda self: self._gain("K"), lambda self, v: self._set_gain("K", v))
+
     def _device(self):
         import torch
         if not torch.cuda.is_available():
@@ -134,7 +151,7 @@ class iLQR(BaseTrajOptimizer):
                 raise ValueError("solver state holds %d problems, this call has %d (use a new iLQR object, "
                                  "or keep the batch size)" % (t.shape[0], B))
             return t.contiguous().clone()
-        return bc(self.delta_, ()), bc(self.k_, (self.N, m)), bc(self.K_, (self.N, m, n))
+        return bc(self.delta_, ()), bc(self._gains["k"], (self.N, m)), bc(self._gains["K"], (self.N, m, n))
 
     def _solve(self, M, O, *args, **kwargs):
         if isinstance(M, _hip.LargeModel):
@@ -191,7 +208,11 @@ class iLQR(BaseTrajOptimizer):
         def out(t, shape=None):
             t = t[0] if single else t
             return t if as_torch else t.cpu().numpy()
-        self.k_, self.K_ = out(k), out(K)
+        # the gains stay on the device (they are the state of the next call); a numpy caller gets
+        # them converted when k_ / K_ is first read
+        self._gains = {"k": k[0] if single else k, "K": K[0] if single else K}
+        self._gains_np = {}
+        self._gains_as_numpy = not as_torch
         self.delta_ = float(delta[0]) if single else out(delta)
         self.mu_ = float(mu[0]) if single else out(mu)
         self.nominal_xs_, self.nominal_us_ = out(xs), out(us)

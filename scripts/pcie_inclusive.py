@@ -27,4 +27,4 @@ for _ in range(3):
     ts.append(time.perf_counter() - t0)
 t = min(ts)
 print("host buffers in and out, %d problems: %.1f ms per batch -> %.0f solves/s (%.1f MB in, %.1f MB out)"
-      % (B, t * 1e3, B / t, (x0.nbytes + us.nbytes) / 1e6, (xs.nbytes + us_out.nbytes + s.K_.nbytes + s.k_.nbytes) / 1e6))
+      % (B, t * 1e3, B / t, (x0.nbytes + us.nbytes) / 1e6, (xs.nbytes + us_out.nbytes) / 1e6))
