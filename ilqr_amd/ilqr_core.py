@@ -30,6 +30,18 @@ def _is_torch(a):
     return type(a).__module__.split(".")[0] == "torch"
 
 
+def _to_numpy(t):
+    """Device tensor -> numpy array through page-locked memory (one copy at PCIe speed; large results
+    through pageable memory run at a fraction of it).  The array owns its page-locked block, which
+    returns to PyTorch's host cache when the array is dropped."""
+    import torch
+    if t.numel() * t.element_size() < (1 << 20):
+        return t.cpu().numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    return h.numpy()
+
+
 class iLQR(BaseTrajOptimizer):
     """Finite Horizon Iterative Linear Quadratic Regulator (ilqr_core.py:30-399)."""
 
@@ -111,7 +123,7 @@ class iLQR(BaseTrajOptimizer):
         v = self._gains[name]
         if _is_torch(v) and self._gains_as_numpy:
             if name not in self._gains_np:
-                self._gains_np[name] = v.cpu().numpy()
+                self._gains_np[name] = _to_numpy(v)
             return self._gains_np[name]
         return v
 
@@ -207,7 +219,7 @@ class iLQR(BaseTrajOptimizer):
 
         def out(t, shape=None):
             t = t[0] if single else t
-            return t if as_torch else t.cpu().numpy()
+            return t if as_torch else _to_numpy(t)
         # the gains stay on the device (they are the state of the next call); a numpy caller gets
         # them converted when k_ / K_ is first read
         self._gains = {"k": k[0] if single else k, "K": K[0] if single else K}
