@@ -215,7 +215,8 @@ class iLQR(BaseTrajOptimizer):
         else:
             xs, us, J, mu, iters, status = self._solve_stepwise(M, kw, n_interations, x0_d, us_d, delta, k, K,
                                                                 on_iteration, single, as_torch)
-        torch.cuda.synchronize()
+        # (no device synchronisation here: tensor callers get results ordered on the current stream,
+        # numpy callers synchronise through the copies below)
 
         def out(t, shape=None):
             t = t[0] if single else t
