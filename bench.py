@@ -214,6 +214,7 @@ def main():
     K = torch.empty((B, T, 1, 5), dtype=torch.float64, device=dev)
     from ilqr_amd import compaction, sharding
     sizes = [B] * world
+    cws = [None]  # workspace of the chunked solve, kept across steps
 
     def step():
         # a freshly constructed solver per step: delta_ = 2, k_ = K_ = 0 (ilqr_core.py:58-65)
@@ -221,7 +222,8 @@ def main():
         k.zero_()
         K.zero_()
         if B >= compaction.COMPACT_MIN_BATCH:  # the product's policy for batches that fill the GPU
-            res = compaction.solve_compacting(_hip.solve, M, {}, O.max_iter, x0, us0, delta=delta, k=k, K=K)
+            res = _hip.solve_chunked(M, O, x0, us0, compaction.COMPACT_CHUNK, delta=delta, k=k, K=K, workspace=cws[0])
+            cws[0] = res["workspace"]
             for name in out_buf:
                 out_buf[name] = res[name]
         else:

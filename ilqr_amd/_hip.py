@@ -66,6 +66,7 @@ EXPORTS = (
     "ilqr_version", "ilqr_status_string", "ilqr_bm_ld", "ilqr_pack_bm", "ilqr_unpack_bm",
     "ilqr_rollout_cost_bm", "ilqr_deriv_bm", "ilqr_backward_bm", "ilqr_forward_ls_bm",
     "ilqr_boxqp_batched", "ilqr_solve_workspace_bytes", "ilqr_solve_batched",
+    "ilqr_solve_chunked_workspace_bytes", "ilqr_solve_batched_chunked",
     "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
     "ilqr_large_rollout_cost", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
     "ilqr_large_solve_batched", "ilqr_large_debug_profile",
@@ -320,6 +321,35 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
         _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),
         C.byref(tr_c) if tr_c is not None else None, _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
     res.update(delta=delta, k=k, K=K, trace=tr, workspace=workspace)
+    return res
+
+
+def solve_chunked(M, O, x0, us_init, chunk, delta=None, k=None, K=None, workspace=None):
+    """ilqr_solve_batched_chunked: launches of ``chunk`` iterations, finished problems dropped in
+    between.  Same dict as ``solve`` (no trace)."""
+    import torch
+    B, dev = x0.shape[0], x0.device
+    T, n, m = M.T, M.n, M.m
+    f64 = torch.float64
+    x0 = _req(x0.reshape(B, n), f64)
+    us_init = _req(us_init.reshape(B, T, m), f64)
+    delta = torch.full((B,), 2.0, dtype=f64, device=dev) if delta is None else delta
+    k = torch.zeros((B, T, m), dtype=f64, device=dev) if k is None else k
+    K = torch.zeros((B, T, m, n), dtype=f64, device=dev) if K is None else K
+    res = dict(xs=torch.empty((B, T + 1, n), dtype=f64, device=dev), us=torch.empty((B, T, m), dtype=f64, device=dev),
+               J=torch.empty(B, dtype=f64, device=dev), mu=torch.empty(B, dtype=f64, device=dev),
+               iters=torch.empty(B, dtype=torch.int32, device=dev), status=torch.empty(B, dtype=torch.int32, device=dev))
+    L = lib()
+    L.ilqr_solve_chunked_workspace_bytes.restype = C.c_size_t
+    need = int(L.ilqr_solve_chunked_workspace_bytes(C.byref(M.c), C.c_int64(B)))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(L.ilqr_solve_batched_chunked(
+        C.byref(M.c), C.byref(O.c), C.c_int32(int(chunk)), C.c_int64(B), _ptr(x0), _ptr(us_init),
+        _ptr(_req(delta, f64)), _ptr(_req(k, f64)), _ptr(_req(K, f64)), _ptr(res["xs"]), _ptr(res["us"]), _ptr(res["J"]),
+        _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]), _ptr(workspace), C.c_size_t(workspace.numel()),
+        _stream()))
+    res.update(delta=delta, k=k, K=K, trace=None, workspace=workspace)
     return res
 
 

@@ -9,7 +9,9 @@ iterations") are gathered into a dense sub-batch and continued from their carrie
 mu, delta and the gains k, K.  A continued launch re-rolls the current controls (same inputs, same
 bits, same cost) and proceeds exactly as the single launch would have: the iterates, iteration
 counts and results are identical (the per-iteration callback mode of ``iLQR.update_u`` relies on the
-same property with chunks of one iteration).  The one state that does not survive a launch boundary
+same property with chunks of one iteration).  For the built-in cart-pole path the same loop exists
+behind the C ABI (``ilqr_solve_batched_chunked``); this module serves the per-model libraries and
+callers that want the per-iteration trace.  The one state that does not survive a launch boundary
 is the pair of expected-improvement sums of the previous backward pass, which the single launch
 re-uses only after a backward pass that has given up on a non-finite Q_uu at mu_max.
 
@@ -92,5 +94,8 @@ def solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=
 def solve_auto(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=None, K=None, trace=False):
     """One launch for batches that do not fill the GPU, chunked launches with compaction above."""
     if x0.shape[0] >= COMPACT_MIN_BATCH and max_iter > 2 * COMPACT_CHUNK:
+        if isinstance(M, _hip.Model) and not trace:  # the built-in path has the same loop behind the C ABI
+            return _hip.solve_chunked(M, _hip.Opts(max_iter=max_iter, **opts_kw), x0, us_init, COMPACT_CHUNK,
+                                      delta=delta, k=k, K=K)
         return solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=delta, k=k, K=K, trace=trace)
     return solve_fn(M, _hip.Opts(max_iter=max_iter, **opts_kw), x0, us_init, delta=delta, k=k, K=K, trace=trace)

@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
+#include <algorithm>
 
 #include "../../include/ilqr_hip.h"
 #include "ilqr_device.hpp"
@@ -1316,6 +1318,181 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
                        (const double*)W.k[1], (const int32_t*)W.sel_gain, k, B, T, tiled);
     hipLaunchKernelGGL(k_unpack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)W.K[0],
                        (const double*)W.K[1], (const int32_t*)W.sel_gain, K, B, T * 5, tiled);
+    return hip_status(hipGetLastError());
+}
+
+
+} // extern "C" (interrupted for the helper kernels of the chunked solve)
+
+namespace {
+
+// dst[j][:] = src[idx[j]][:] and back, rows of `row` doubles (reference-layout per-problem arrays)
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ src, double* __restrict__ dst,
+                                                     const int64_t* __restrict__ idx, int64_t n, int64_t row)
+{
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * row)
+        return;
+    int64_t j = e / row, c = e - j * row;
+    dst[e] = src[idx[j] * row + c];
+}
+__global__ __launch_bounds__(256) void k_scatter_rows(const double* __restrict__ src, double* __restrict__ dst,
+                                                      const int64_t* __restrict__ idx, int64_t n, int64_t row)
+{
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * row)
+        return;
+    int64_t j = e / row, c = e - j * row;
+    dst[idx[j] * row + c] = src[e];
+}
+// iteration counts add up over the launches, the status is that of the last launch a problem took part in
+__global__ __launch_bounds__(256) void k_chunk_bookkeeping(const int32_t* __restrict__ iters_c,
+                                                           const int32_t* __restrict__ status_c,
+                                                           const int64_t* __restrict__ idx, int64_t n,
+                                                           int32_t* __restrict__ iters, int32_t* __restrict__ status)
+{
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n)
+        return;
+    int64_t b = idx ? idx[j] : j;
+    iters[b] += iters_c[j];
+    status[b] = status_c[j];
+}
+__global__ __launch_bounds__(256) void k_chunk_init(int64_t B, double* __restrict__ mu, int32_t* __restrict__ iters,
+                                                    int32_t* __restrict__ status)
+{
+    int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B)
+        return;
+    mu[b] = 1.0; // update_u resets mu per call (ilqr_core.py:264)
+    iters[b] = 0;
+    status[b] = ILQR_RAN_OUT;
+}
+
+inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+struct ChunkBuffers { // carved out of the caller's workspace behind the solve workspace
+    double *x0, *us, *delta, *k, *K, *mu, *xs, *J;
+    int32_t *iters, *status;
+    int64_t* idx;
+};
+
+} // namespace
+
+extern "C" {
+
+size_t ilqr_solve_chunked_workspace_bytes(const ilqr_model* model, int64_t B)
+{
+    size_t base = ilqr_solve_workspace_bytes(model, B);
+    if (base == 0)
+        return 0;
+    int64_t T = model->T;
+    // gathered copies of every per-problem array + iteration counts, status and the index list
+    size_t doubles = (size_t)B * (5 + T + 1 + T + T * 5 + 1 + (T + 1) * 5 + 1);
+    return base + doubles * sizeof(double) + (size_t)B * (2 * sizeof(int32_t) + sizeof(int64_t)) + 256;
+}
+
+int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, int32_t chunk, int64_t B,
+                               const double* x0, const double* us_init, double* delta, double* k, double* K,
+                               double* xs, double* us, double* J, double* mu, int32_t* iters, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream)
+{
+    int rc = check_model(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (!opts || chunk < 1 || !x0 || !us_init || !delta || !k || !K || !xs || !us || !J || !mu || !iters ||
+        !status || !workspace || B < 1)
+        return ILQR_ERR_ARG;
+    if (workspace_bytes < ilqr_solve_chunked_workspace_bytes(model, B))
+        return ILQR_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int64_t T = model->T;
+    const size_t base = (ilqr_solve_workspace_bytes(model, B) + 255) / 256 * 256;
+    ChunkBuffers G;
+    {
+        double* p = reinterpret_cast<double*>(static_cast<char*>(workspace) + base);
+        G.x0 = p; p += B * 5;
+        G.us = p; p += B * T;
+        G.delta = p; p += B;
+        G.k = p; p += B * T;
+        G.K = p; p += B * T * 5;
+        G.mu = p; p += B;
+        G.xs = p; p += B * (T + 1) * 5;
+        G.J = p; p += B;
+        G.idx = reinterpret_cast<int64_t*>(p);
+        G.iters = reinterpret_cast<int32_t*>(G.idx + B);
+        G.status = G.iters + B;
+    }
+    ilqr_opts o = *opts;
+    o.mu_init = 0.0; // every launch starts from the mu array
+    hipLaunchKernelGGL(k_chunk_init, dim3(blocks256(B)), dim3(256), 0, st, B, mu, iters, status);
+    std::vector<int32_t> h_status((size_t)B);
+    std::vector<int64_t> h_idx;
+    int64_t n = B;      // problems still running
+    bool full = true;   // all of them: the launches work on the caller's arrays in place
+    int done = 0;
+    const int max_iter = opts->max_iter;
+    for (;;) {
+        o.max_iter = std::min<int>(chunk, max_iter - done);
+        if (full) {
+            // (us may alias us_init from the second launch on: the input is packed before the output is written)
+            rc = ilqr_solve_batched(model, &o, B, x0, done == 0 ? us_init : us, delta, k, K, xs, us, J, mu, G.iters,
+                                    G.status, nullptr, workspace, base, stream);
+            if (rc != ILQR_OK)
+                return rc;
+            hipLaunchKernelGGL(k_chunk_bookkeeping, dim3(blocks256(B)), dim3(256), 0, st, G.iters, G.status,
+                               (const int64_t*)nullptr, B, iters, status);
+        } else {
+            auto gather = [&](const double* src, double* dst, int64_t row) {
+                hipLaunchKernelGGL(k_gather_rows, dim3(blocks256(n * row)), dim3(256), 0, st, src, dst, G.idx, n, row);
+            };
+            auto scatter = [&](const double* src, double* dst, int64_t row) {
+                hipLaunchKernelGGL(k_scatter_rows, dim3(blocks256(n * row)), dim3(256), 0, st, src, dst, G.idx, n, row);
+            };
+            gather(x0, G.x0, 5);
+            gather(us, G.us, T);
+            gather(delta, G.delta, 1);
+            gather(k, G.k, T);
+            gather(K, G.K, T * 5);
+            gather(mu, G.mu, 1);
+            rc = ilqr_solve_batched(model, &o, n, G.x0, G.us, G.delta, G.k, G.K, G.xs, G.us, G.J, G.mu, G.iters,
+                                    G.status, nullptr, workspace, base, stream);
+            if (rc != ILQR_OK)
+                return rc;
+            scatter(G.xs, xs, (T + 1) * 5);
+            scatter(G.us, us, T);
+            scatter(G.J, J, 1);
+            scatter(G.delta, delta, 1);
+            scatter(G.k, k, T);
+            scatter(G.K, K, T * 5);
+            scatter(G.mu, mu, 1);
+            hipLaunchKernelGGL(k_chunk_bookkeeping, dim3(blocks256(n)), dim3(256), 0, st, G.iters, G.status,
+                               (const int64_t*)G.idx, n, iters, status);
+        }
+        done += o.max_iter;
+        if (done >= max_iter)
+            break;
+        // who is still running?  (one small read-back per chunk: the next launch is sized on the host)
+        if (hipMemcpyAsync(h_status.data(), G.status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st) !=
+                hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return ILQR_ERR_HIP;
+        std::vector<int64_t> next;
+        next.reserve((size_t)n);
+        for (int64_t j = 0; j < n; ++j)
+            if (h_status[(size_t)j] == ILQR_RAN_OUT)
+                next.push_back(full ? j : h_idx[(size_t)j]);
+        if (full && (int64_t)next.size() == B)
+            continue;
+        full = false;
+        h_idx.swap(next);
+        n = (int64_t)h_idx.size();
+        if (n == 0)
+            break;
+        if (hipMemcpyAsync(G.idx, h_idx.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) // (h_idx is reused by the next round)
+            return ILQR_ERR_HIP;
+    }
     return hip_status(hipGetLastError());
 }
 

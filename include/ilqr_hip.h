@@ -178,6 +178,21 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
                        const ilqr_trace* trace, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* The same solve for batches that fill the GPU, cut into launches of `chunk` iterations: after each
+ * launch the problems whose update_u loop has ended (converged, mu >= mu_max: ilqr_core.py:325-339)
+ * are dropped and the rest continues as a dense sub-batch from its carried state (controls, mu,
+ * delta, k, K), so that finished problems stop costing lanes and memory traffic.  Results are those
+ * of ilqr_solve_batched (a continued launch re-rolls the current controls: same inputs, same bits).
+ * No counterpart in the reference, which solves one problem at a time.  Arguments as
+ * ilqr_solve_batched without the trace; the workspace is larger (gathered copies of the per-problem
+ * arrays); us may alias us_init.  Synchronises the stream once per chunk (the next launch is sized
+ * on the host), so it is not capturable in a HIP graph. */
+size_t ilqr_solve_chunked_workspace_bytes(const ilqr_model* model, int64_t B);
+int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, int32_t chunk, int64_t B,
+                               const double* x0, const double* us_init, double* delta, double* k, double* K,
+                               double* xs, double* us, double* J, double* mu, int32_t* iters, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* CartPoleContinuousEnv._state_eq (ilqr/cartpole_gym.py:60-72), the plant the MPC
  * example steps: st [B,4] = [x, x', theta, theta'], u [B] -> out [B,4].
  * par HOST [5] = gravity, masscart, masspole, length, tau. */

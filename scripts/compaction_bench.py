@@ -32,6 +32,9 @@ def timed(fn, reps=2):
 t1, a = timed(lambda: _hip.solve(M, _hip.Opts(max_iter=200), x0, us))
 print("B=%d single launch: %.1f ms, %.0f solves/s" % (B, t1 * 1e3, B / t1))
 for c in chunks:
+    tc, b = timed(lambda: _hip.solve_chunked(M, _hip.Opts(max_iter=200), x0, us, c))
+    same = all(torch.equal(a[k], b[k]) for k in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K"))
+    print("   C entry point, chunks of %3d: %.1f ms, %.0f solves/s, identical results: %s" % (c, tc * 1e3, B / tc, same))
     tc, b = timed(lambda: compaction.solve_compacting(_hip.solve, M, {}, 200, x0, us, chunk=c))
     same = all(torch.equal(a[k], b[k]) for k in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K"))
     print("   chunks of %3d iterations: %.1f ms, %.0f solves/s, identical results: %s" % (c, tc * 1e3, B / tc, same))

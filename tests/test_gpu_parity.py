@@ -546,3 +546,26 @@ def test_chunked_solve_with_compaction_equals_single_launch(hip, B, chunk):
     ref = co.solve(Mo, co.Opts(max_iter=60), x0[:40], us0[:40], nthreads=8)
     assert eq(chunked["xs"][:40].cpu().numpy(), ref["xs"]) and np.array_equal(it[:40], ref["iters"])
     assert (it < 60).any() and (it == 60).any()
+
+
+@pytest.mark.parametrize("B,chunk", [(3000, 7), (100, 1), (70, 500)])
+def test_c_level_chunked_solve_equals_single_launch(hip, B, chunk):
+    """ilqr_solve_batched_chunked (launches of `chunk` iterations, finished problems dropped in between,
+    the loop behind the C ABI) returns what ilqr_solve_batched returns, bit for bit."""
+    Mo = co.cartpole_model()
+    M = hip_model(hip, Mo)
+    x0, us0 = co.cartpole_batch(B, seed_x=73, seed_u=74)
+    one = hip.solve(M, hip.Opts(max_iter=60), dev(x0), dev(us0))
+    chunked = hip.solve_chunked(M, hip.Opts(max_iter=60), dev(x0), dev(us0), chunk)
+    torch.cuda.synchronize()
+    for key in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K"):
+        assert torch.equal(one[key], chunked[key]), key
+    it = one["iters"].cpu().numpy()
+    assert (it < 60).any() and (it == 60).any()
+    # carried solver state: a second call continues from delta/k/K exactly like the single launch
+    one2 = hip.solve(M, hip.Opts(max_iter=20), one["xs"][:, 0].contiguous(), one["us"], delta=one["delta"], k=one["k"],
+                     K=one["K"])
+    ch2 = hip.solve_chunked(M, hip.Opts(max_iter=20), chunked["xs"][:, 0].contiguous(), chunked["us"], 6,
+                            delta=chunked["delta"], k=chunked["k"], K=chunked["K"])
+    for key in ("xs", "us", "J", "iters", "status", "K"):
+        assert torch.equal(one2[key], ch2[key]), key
