@@ -100,6 +100,7 @@ __device__ __forceinline__ QPOptsP qp_opts_in_vgprs(const QPOptsP& o)
 struct SolveOptsP {
     int max_iter, n_alpha;
     int mu_from_array; // 0: mu starts at 1.0 (ilqr_core.py:264); 1: at mu_out[b]
+    int lanes_per_wave; // problems handled by one wavefront of the solve kernel (64, 32 or 16)
     double tol, scale, mu_min, mu_max, delta0;
     double alphas[32];
     QPOptsP qp;

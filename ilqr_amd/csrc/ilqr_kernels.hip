@@ -583,9 +583,14 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     __shared__ int s_lane[4][LS_PASS], s_cur[4][LS_PASS], s_gcur[4][LS_PASS];
     __shared__ double s_qp_tab[QP_TAB];
 
-    const int64_t gb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // problem index
-    const bool valid = gb < B;
+    // problems per wavefront (64, 32 or 16): a small batch is spread thinly over all SIMDs, which costs a
+    // wave nothing (an instruction takes as long for 16 lanes as for 64) and makes the wave-level slow
+    // paths (boxQP fallbacks, the cooperative line search) rarer per wave
     const int lane = threadIdx.x & 63;
+    const int lpw = O.lanes_per_wave;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t gb = wave_global * lpw + lane; // problem index
+    const bool valid = lane < lpw && gb < B;
     const int wv = threadIdx.x >> 6; // wave within the workgroup (each wave only talks to itself)
     if (threadIdx.x < LS_MAXA)
         s_alpha[threadIdx.x] = O.alphas[threadIdx.x];
@@ -597,14 +602,14 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        wave_log[(gb >> 6) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-        wave_log[(gb >> 6) * 4 + 2] = hw_id;
-        wave_log[(gb >> 6) * 4 + 3] = xcc;
+        wave_log[wave_global * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        wave_log[wave_global * 4 + 2] = hw_id;
+        wave_log[wave_global * 4 + 3] = xcc;
     }
     // the workspace is wave-tiled: this wave's rows are contiguous, leading dimension 64.
     // (Named pointers and selects, not arrays indexed by a lane-varying 0/1: a
     // dynamically indexed pointer array would live in scratch memory.)
-    const int64_t tile = gb >> 6;
+    const int64_t tile = (wave_global * lpw) >> 6; // wave-uniform: the helper lanes of the line search use it too
     double* const xs0 = W.xs[0] + tile * (int64_t)(T + 1) * NX * 64;
     double* const xs1 = W.xs[1] + tile * (int64_t)(T + 1) * NX * 64;
     double* const us0 = W.us[0] + tile * (int64_t)T * 64;
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
 #define KF(i) ((i) ? k1 : k0)
 #define KG(i) ((i) ? K1 : K0)
     const int64_t ld = 64;
-    const int64_t b = lane;
+    const int64_t b = gb & 63; // column of the problem in its tile
     CartpoleC P = cartpole_consts(mp);
     Cost C(Cp);
     QPOptsP QO = qp_opts_in_vgprs(O.qp);
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
             int rank = __popcll(mask & ((1ull << lane) - 1ull));
             bool mine = need && rank < LS_PASS;
             if (mine) {
-                s_lane[wv][rank] = lane;
+                s_lane[wv][rank] = (int)b;
                 s_cur[wv][rank] = cur;
                 s_gcur[wv][rank] = gcur;
             }
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         W.sel_gain[gb] = gcur;
     }
     if (wave_log != nullptr && lane == 0 && valid)
-        wave_log[(gb >> 6) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        wave_log[wave_global * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #undef XS
 #undef US
 #undef KF
@@ -1038,6 +1043,7 @@ int fill_opts(const ilqr_opts* o, SolveOptsP& s)
     s.max_iter = o->max_iter;
     s.n_alpha = o->n_alpha;
     s.mu_from_array = (o->mu_init >= 0.0) ? 1 : 0;
+    s.lanes_per_wave = WAVE;
     s.tol = o->tol;
     s.scale = o->scale;
     s.mu_min = o->mu_min;
@@ -1293,12 +1299,23 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
-    // Workgroup shape: one wave per workgroup spreads a small batch over all CUs; with
-    // more than one wave per CU to place, 4-wave workgroups put one wave on each SIMD.
-    int blk = B > 64 * 256 ? 256 : WAVE;
+    // Problems per wavefront: 32 while every wave still finds a free wavefront slot (1024 = 256 CUs x
+    // 4 SIMDs, one wave each), 64 beyond.  Measured at 16384 problems: 72 ms with 64, 65.6 ms with 32;
+    // 16 per wave is no faster there and far slower once the waves outnumber the slots.
+    int lpw = B <= 32 * 1024 ? 32 : WAVE;
+    if (const char* e = std::getenv("ILQR_SOLVE_LPW")) {
+        int v = std::atoi(e);
+        lpw = (v == 16 || v == 32) ? v : WAVE;
+    }
+    O.lanes_per_wave = lpw;
+    const int64_t nwaves = (B + lpw - 1) / lpw;
+    // Workgroup shape: waves that share a workspace tile (64 / lpw of them) must sit in one workgroup,
+    // i.e. on one CU: sharing a tile across XCDs was measured 10 % slower.  Otherwise one wave per
+    // workgroup spreads a small batch over all CUs, and 4-wave workgroups put one wave on each SIMD.
+    int blk = (lpw < WAVE || nwaves > 256) ? 256 : WAVE;
     if (const char* e = std::getenv("ILQR_SOLVE_BLOCK"))
         blk = std::atoi(e) == 256 ? 256 : WAVE;
-    dim3 grid((unsigned)((B + blk - 1) / blk));
+    dim3 grid((unsigned)((nwaves * WAVE + blk - 1) / blk));
     int ev = cost_eval(C);
 #define ILQR_LAUNCH_SOLVE(COST)                                                                               \
     hipLaunchKernelGGL((k_solve<COST>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, iters, \

@@ -1153,6 +1153,7 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
     O.max_iter = opts->max_iter;
     O.n_alpha = opts->n_alpha;
     O.mu_from_array = (opts->mu_init >= 0.0) ? 1 : 0;
+    O.lanes_per_wave = 64;
     O.tol = opts->tol;
     O.scale = opts->scale;
     O.mu_min = opts->mu_min;

@@ -14,7 +14,8 @@ Q, R, Qt, xg = bench.cartpole_cost()
 M = _hip.Model(100, Q, R, Qt, xg, None, [-5.0], [5.0])
 x0_h, us_h = bench.make_batch(B, 0)
 x0 = torch.tensor(x0_h, device=dev); us = torch.tensor(us_h, device=dev)
-nw = (B + 63) // 64
+lpw = int(os.environ.get("ILQR_SOLVE_LPW", 32 if B <= 32768 else 64))  # as the library chooses
+nw = (B + lpw - 1) // lpw
 log = torch.zeros((nw, 4), dtype=torch.int64, device=dev)
 O = _hip.Opts()
 _hip.solve(M, O, x0, us); torch.cuda.synchronize()
@@ -42,7 +43,7 @@ key = L[:, 3] * 100000 + se * 10000 + sh * 1000 + cu * 10 + simd
 first = start < 1
 print("distinct SIMDs used by waves started in the first ms:", len(np.unique(key[first])), "of", int(first.sum()), "waves")
 print("distinct CUs:", len(np.unique(key[first] // 10)))
-iters = res["iters"].cpu().numpy().reshape(nw, -1).max(axis=1)
+iters = res["iters"].cpu().numpy()[:nw * lpw].reshape(nw, -1).max(axis=1) if B % lpw == 0 else res["iters"].cpu().numpy()
 print("per-wave max iterations: min %d mean %.1f" % (iters.min(), iters.mean()))
 # wave lifetime by how many waves share the wave's CU / SIMD
 cukey = key // 10
