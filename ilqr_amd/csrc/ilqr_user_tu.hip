@@ -382,7 +382,7 @@ constexpr int ULS_MAXA = 32; // largest alpha schedule
 // costs into LDS) and then scan the costs in the reference's order.  A rollout is a pure function
 // of (problem, alpha), so decisions and numbers are those of the serial loop; a rejected
 // iteration costs ~3 rollout times instead of 30.
-__global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C, SolveOptsP O, UBounds bd, int T, int64_t B,
+__global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C_arg, SolveOptsP O, UBounds bd, int T, int64_t B,
                                                    double* ws, const double* x0, const double* us_init,
                                                    double* delta_io, double* k_io, double* K_io, double* xs_out,
                                                    double* us_out, double* J_out, double* mu_out,
@@ -392,7 +392,14 @@ __global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C, SolveOpts
     __shared__ double s_alpha[ULS_MAXA];
     __shared__ double s_J[ULS_PASS][ULS_MAXA];
     __shared__ int s_lane[ULS_PASS], s_cur[ULS_PASS], s_gcur[ULS_PASS];
+    // The cost matrices are read from LDS (wave-uniform addresses): held in scalar registers for the whole
+    // kernel, their ~220 registers were spilled to vector-register lanes and a quarter of all vector
+    // instructions were the lane reads that fetched them back.
+    __shared__ UCost s_cost;
     const int lane = threadIdx.x;
+    if (lane == 0)
+        s_cost = C_arg;
+    const UCost& C = s_cost;
     if (lane < ULS_MAXA)
         s_alpha[lane] = O.alphas[lane];
     qp_fill_step_table(s_qp_tab, O.qp.step_dec); // ends with the workgroup barrier
@@ -919,13 +926,19 @@ __device__ __forceinline__ UWork utile(double* ws, int64_t tile, int64_t T)
 }
 
 // iLQR.update_u (ilqr_core.py:241-399), every lane its own problem, serial first-hit line search.
-__global__ __launch_bounds__(64) void k_user_solve_m(UParams P, GCost C, SolveOptsP O, GBounds bd, int T, int64_t B,
+__global__ __launch_bounds__(64) void k_user_solve_m(UParams P, GCost C_arg, SolveOptsP O, GBounds bd, int T, int64_t B,
                                                      double* ws, const double* x0, const double* us_init,
                                                      double* delta_io, double* k_io, double* K_io, double* xs_out,
                                                      double* us_out, double* J_out, double* mu_out,
                                                      int32_t* iters_out, int32_t* status_out, ilqr_trace tr)
 {
     const int lane = threadIdx.x;
+    // the cost matrices are read from LDS (wave-uniform addresses) instead of occupying scalar registers
+    __shared__ GCost s_cost;
+    if (lane == 0)
+        s_cost = C_arg;
+    const GCost& C = s_cost;
+    __syncthreads();
     // problems per wavefront: the first O.lanes_per_wave columns of the wave's 64-column tile are in use
     const int64_t b = (int64_t)blockIdx.x * O.lanes_per_wave + lane;
     if (lane >= O.lanes_per_wave || b >= B)
