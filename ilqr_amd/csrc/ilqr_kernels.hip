@@ -1299,22 +1299,31 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
-    // Problems per wavefront: 32 while every wave still finds a free wavefront slot (1024 = 256 CUs x
-    // 4 SIMDs, one wave each), 64 beyond.  Measured at 16384 problems: 72 ms with 64, 65.6 ms with 32;
-    // 16 per wave is no faster there and far slower once the waves outnumber the slots.
-    int lpw = B <= 32 * 1024 ? 32 : WAVE;
+    // Launch shape.  Measured with per-wave timestamps at 16384 problems: when every CU runs one wave,
+    // waves on certain CUs (the same hardware positions in every run) take up to 10 % longer than the
+    // median and set the kernel time (72 ms); packed four to a CU on a quarter of the CUs, the same waves
+    // finish within 3 % of each other (66.6 ms).  So long solves use 4-wave workgroups at every batch
+    // size, and 32 problems per wavefront while every wave still finds a free SIMD (1024 of them): a
+    // wave-level slow path is entered when any lane needs it, and an instruction costs the same for 32
+    // lanes as for 64 (65.9 ms; 16 per wave is no faster and far slower once waves outnumber the SIMDs).
+    // Short launches (the re-solves of a closed loop: T = 15, 10 iterations) measured 8 % faster with one
+    // full wave per workgroup and keep that shape.
+    const bool short_launch = (int64_t)T * O.max_iter < 2048;
+    int lpw = (B <= 32 * 1024 && !short_launch) ? 32 : WAVE;
     if (const char* e = std::getenv("ILQR_SOLVE_LPW")) {
         int v = std::atoi(e);
         lpw = (v == 16 || v == 32) ? v : WAVE;
     }
     O.lanes_per_wave = lpw;
     const int64_t nwaves = (B + lpw - 1) / lpw;
-    // Workgroup shape: waves that share a workspace tile (64 / lpw of them) must sit in one workgroup,
-    // i.e. on one CU: sharing a tile across XCDs was measured 10 % slower.  Otherwise one wave per
-    // workgroup spreads a small batch over all CUs, and 4-wave workgroups put one wave on each SIMD.
-    int blk = (lpw < WAVE || nwaves > 256) ? 256 : WAVE;
-    if (const char* e = std::getenv("ILQR_SOLVE_BLOCK"))
-        blk = std::atoi(e) == 256 ? 256 : WAVE;
+    // Waves that share a workspace tile (64 / lpw of them) must sit in one workgroup, i.e. on one CU:
+    // sharing a tile across XCDs was measured 10 % slower.
+    int blk = (lpw == WAVE && short_launch && nwaves <= 256) ? WAVE : 256;
+    if (const char* e = std::getenv("ILQR_SOLVE_BLOCK")) {
+        int v = std::atoi(e);
+        if (v == 256 || v == 128 || (v == WAVE && lpw == WAVE))
+            blk = v;
+    }
     dim3 grid((unsigned)((nwaves * WAVE + blk - 1) / blk));
     int ev = cost_eval(C);
 #define ILQR_LAUNCH_SOLVE(COST)                                                                               \

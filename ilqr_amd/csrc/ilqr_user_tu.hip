@@ -47,6 +47,7 @@ using namespace ilqr;
 
 constexpr int UN = ILQR_USER_N;
 constexpr int UM = ILQR_USER_M;
+constexpr int UWG = 4; // most wavefronts per workgroup of the solve kernels
 constexpr int UNP = ILQR_USER_NP > 0 ? ILQR_USER_NP : 1;
 static_assert(UN >= 1 && UN <= 8, "ILQR_USER_N must be between 1 and 8");
 static_assert(UM >= 1 && UM <= 4, "ILQR_USER_M must be between 1 and 4");
@@ -382,7 +383,7 @@ constexpr int ULS_MAXA = 32; // largest alpha schedule
 // costs into LDS) and then scan the costs in the reference's order.  A rollout is a pure function
 // of (problem, alpha), so decisions and numbers are those of the serial loop; a rejected
 // iteration costs ~3 rollout times instead of 30.
-__global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C_arg, SolveOptsP O, UBounds bd, int T, int64_t B,
+__global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, SolveOptsP O, UBounds bd, int T, int64_t B,
                                                    double* ws, const double* x0, const double* us_init,
                                                    double* delta_io, double* k_io, double* K_io, double* xs_out,
                                                    double* us_out, double* J_out, double* mu_out,
@@ -390,23 +391,30 @@ __global__ __launch_bounds__(64) void k_user_solve(UParams P, UCost C_arg, Solve
 {
     __shared__ double s_qp_tab[QP_TAB];
     __shared__ double s_alpha[ULS_MAXA];
-    __shared__ double s_J[ULS_PASS][ULS_MAXA];
-    __shared__ int s_lane[ULS_PASS], s_cur[ULS_PASS], s_gcur[ULS_PASS];
+    // four wavefronts per workgroup, each with its own slice of the line-search arrays (a wave only talks
+    // to itself): packed four to a CU the waves of a small batch run more evenly than one per CU
+    __shared__ double s_J_all[UWG][ULS_PASS][ULS_MAXA];
+    __shared__ int s_lane_all[UWG][ULS_PASS], s_cur_all[UWG][ULS_PASS], s_gcur_all[UWG][ULS_PASS];
     // The cost matrices are read from LDS (wave-uniform addresses): held in scalar registers for the whole
     // kernel, their ~220 registers were spilled to vector-register lanes and a quarter of all vector
     // instructions were the lane reads that fetched them back.
     __shared__ UCost s_cost;
-    const int lane = threadIdx.x;
-    if (lane == 0)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double(&s_J)[ULS_PASS][ULS_MAXA] = s_J_all[wv];
+    int(&s_lane)[ULS_PASS] = s_lane_all[wv];
+    int(&s_cur)[ULS_PASS] = s_cur_all[wv];
+    int(&s_gcur)[ULS_PASS] = s_gcur_all[wv];
+    if (threadIdx.x == 0)
         s_cost = C_arg;
     const UCost& C = s_cost;
-    if (lane < ULS_MAXA)
-        s_alpha[lane] = O.alphas[lane];
+    if (threadIdx.x < ULS_MAXA)
+        s_alpha[threadIdx.x] = O.alphas[threadIdx.x];
     qp_fill_step_table(s_qp_tab, O.qp.step_dec); // ends with the workgroup barrier
     // problems per wavefront: the first O.lanes_per_wave columns of the wave's 64-column tile are in use
-    const int64_t b = (int64_t)blockIdx.x * O.lanes_per_wave + lane;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const int64_t b = tile * O.lanes_per_wave + lane;
     const bool valid = lane < O.lanes_per_wave && b < B;
-    const UWork W = utile(ws, blockIdx.x, T);
+    const UWork W = utile(ws, tile, T);
     const int64_t ld = 64, bl = lane; // row stride and column inside the tile
 #define XS(i) ((i) ? W.xs1 : W.xs0)
 #define US(i) ((i) ? W.us1 : W.us0)
@@ -926,24 +934,26 @@ __device__ __forceinline__ UWork utile(double* ws, int64_t tile, int64_t T)
 }
 
 // iLQR.update_u (ilqr_core.py:241-399), every lane its own problem, serial first-hit line search.
-__global__ __launch_bounds__(64) void k_user_solve_m(UParams P, GCost C_arg, SolveOptsP O, GBounds bd, int T, int64_t B,
+__global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg, SolveOptsP O, GBounds bd, int T, int64_t B,
                                                      double* ws, const double* x0, const double* us_init,
                                                      double* delta_io, double* k_io, double* K_io, double* xs_out,
                                                      double* us_out, double* J_out, double* mu_out,
                                                      int32_t* iters_out, int32_t* status_out, ilqr_trace tr)
 {
-    const int lane = threadIdx.x;
+    // one or four wavefronts per workgroup (the host chooses)
+    const int lane = threadIdx.x & 63;
     // the cost matrices are read from LDS (wave-uniform addresses) instead of occupying scalar registers
     __shared__ GCost s_cost;
-    if (lane == 0)
+    if (threadIdx.x == 0)
         s_cost = C_arg;
     const GCost& C = s_cost;
     __syncthreads();
     // problems per wavefront: the first O.lanes_per_wave columns of the wave's 64-column tile are in use
-    const int64_t b = (int64_t)blockIdx.x * O.lanes_per_wave + lane;
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t b = tile * O.lanes_per_wave + lane;
     if (lane >= O.lanes_per_wave || b >= B)
         return;
-    const UWork W = utile(ws, blockIdx.x, T);
+    const UWork W = utile(ws, tile, T);
     const int64_t bl = lane;
 #define XS(i) ((i) ? W.xs1 : W.xs0)
 #define US(i) ((i) ? W.us1 : W.us0)
@@ -1080,18 +1090,30 @@ int ucheck(const ilqr_user_model* m)
     return ILQR_OK;
 }
 
-// Problems per wavefront.  The multi-control kernel runs the line search serially per lane, so a wave is as
-// slow as its slowest lane: half-filled waves while every wave still finds a free SIMD (1024 of them) were
-// measured 11 % faster at 16384 problems (an instruction costs the same for 32 lanes as for 64).  The
-// single-control kernel, whose line search is cooperative, measured 10 % slower that way and keeps 64.
+// Problems per wavefront: half-filled waves while every wave still finds a free SIMD (1024 of them).  A wave
+// runs as long as its slowest lane, and an instruction costs the same for 32 lanes as for 64.
 int ulanes(int64_t B)
 {
-    int lpw = (UM > 1 && B <= 32 * 1024) ? 32 : 64;
+    int lpw = B <= 32 * 1024 ? 32 : 64;
     if (const char* e = std::getenv("ILQR_SOLVE_LPW")) {
         int v = std::atoi(e);
         lpw = (v == 16 || v == 32) ? v : 64;
     }
     return lpw;
+}
+// Wavefronts per workgroup.  The single-control kernel runs 3-5 % faster with four waves on one CU than
+// with one wave on each of four CUs (as the built-in cart-pole kernel does).  The multi-control kernel,
+// which spills to scratch memory and leans on the CU's vector cache, is 18 % slower that way while CUs
+// are free; once every CU holds four waves anyway the two shapes measure alike.
+int uwaves_per_group(int64_t nwaves)
+{
+    int w = (UM > 1 && nwaves < 1024) ? 1 : UWG;
+    if (const char* e = std::getenv("ILQR_SOLVE_BLOCK")) {
+        int v = std::atoi(e);
+        if (v == 64 || v == 256)
+            w = v / 64;
+    }
+    return w;
 }
 int64_t utiles(int64_t B) { int lpw = ulanes(B); return (B + lpw - 1) / lpw; }
 int64_t uld(int64_t B) { return utiles(B) * 64; }
@@ -1218,7 +1240,8 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
 #if ILQR_USER_M > 1
 #define k_user_solve k_user_solve_m
 #endif
-    hipLaunchKernelGGL(k_user_solve, dim3((unsigned)utiles(B)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+    const int wpg = uwaves_per_group(utiles(B));
+    hipLaunchKernelGGL(k_user_solve, dim3((unsigned)((utiles(B) + wpg - 1) / wpg)), dim3(64 * wpg), 0, reinterpret_cast<hipStream_t>(stream),
                        P, C, O, bd, (int)T, B, static_cast<double*>(workspace), x0, us_init, delta, k, K, xs, us, J, mu,
                        iters, status, tr);
     return hipGetLastError() == hipSuccess ? ILQR_OK : ILQR_ERR_HIP;

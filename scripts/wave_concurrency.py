@@ -72,3 +72,9 @@ if qp_wave:
     A_ = np.stack([np.ones(nw), qw[0], qw[1]], 1)
     coef = np.linalg.lstsq(A_, life_, rcond=None)[0]
     print("least squares: life = %.1f ms + %.2f us per fallback + %.2f us per rejected block" % (coef[0], coef[1] * 1e3, coef[2] * 1e3))
+
+print("slowest waves (wave, life ms, xcc, se, sh, cu, simd):")
+for w in np.argsort(-life)[:10]:
+    print("   %5d %.1f  xcc %d se %d sh %d cu %2d simd %d" % (w, life[w], xcc[w], se[w], sh[w], cu[w], simd[w]))
+print("mean life by XCC:", " ".join("%.1f" % life[xcc == i].mean() for i in range(8)))
+print("mean life by CU id:", " ".join("%d:%.1f" % (i, life[cu == i].mean()) for i in np.unique(cu)))
