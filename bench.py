@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if os.environ.get("ILQR_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ILQR_BENCH_WATCHDOG"]), exit=True)
     if args.workload == "large":
         return main_large(args)
 
@@ -189,11 +192,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, args.gpus))
+    # ILQR_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
+    # (ranks share devices; RCCL refuses that).  The measured configuration is always nccl (= RCCL).
+    backend = os.environ.get("ILQR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.batch if args.batch is not None else B_PER_GPU
     Q, R, Qt, xg = cartpole_cost()
@@ -203,20 +214,29 @@ def main():
     x0 = torch.tensor(x0_h, device=dev)
     us0 = torch.tensor(us_h, device=dev)
     ws = torch.empty(_hip.solve_workspace_bytes(M, B), dtype=torch.uint8, device=dev)
-    out_buf = dict(xs=torch.empty((B, T + 1, 5), dtype=torch.float64, device=dev),
-                   us=torch.empty((B, T, 1), dtype=torch.float64, device=dev),
-                   J=torch.empty(B, dtype=torch.float64, device=dev),
-                   mu=torch.empty(B, dtype=torch.float64, device=dev),
-                   iters=torch.empty(B, dtype=torch.int32, device=dev),
-                   status=torch.empty(B, dtype=torch.int32, device=dev))
+    # Result tensors: with more than one rank two sets alternate, so that the gather of one solve's
+    # results (on the collective's stream) overlaps the next solve.
+    n_sets = 2 if world > 1 else 1
+    out_sets = [dict(xs=torch.empty((B, T + 1, 5), dtype=torch.float64, device=dev),
+                     us=torch.empty((B, T, 1), dtype=torch.float64, device=dev),
+                     J=torch.empty(B, dtype=torch.float64, device=dev),
+                     mu=torch.empty(B, dtype=torch.float64, device=dev),
+                     iters=torch.empty(B, dtype=torch.int32, device=dev),
+                     status=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
     delta = torch.empty(B, dtype=torch.float64, device=dev)
     k = torch.empty((B, T, 1), dtype=torch.float64, device=dev)
     K = torch.empty((B, T, 1, 5), dtype=torch.float64, device=dev)
     from ilqr_amd import compaction, sharding
-    sizes = [B] * world
     cws = [None]  # workspace of the chunked solve, kept across steps
+    pipe = sharding.GatherPipeline(depth=n_sets, dst=0) if world > 1 else None
+    n_steps = [0]
 
     def step():
+        slot = n_steps[0] % n_sets
+        n_steps[0] += 1
+        out_buf = out_sets[slot]
+        if pipe is not None:
+            pipe.reclaim(slot)  # the set's previous gather is ordered before the solve that overwrites it
         # a freshly constructed solver per step: delta_ = 2, k_ = K_ = 0 (ilqr_core.py:58-65)
         delta.fill_(2.0)
         k.zero_()
@@ -228,12 +248,16 @@ def main():
                 out_buf[name] = res[name]
         else:
             res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws, out=out_buf)
-        if world > 1:  # the only exchange of the path: results to rank 0 over xGMI
-            for name in ("J", "iters", "status", "xs", "us"):
-                sharding.gather_to_root(out_buf[name], sizes, dst=0)
+        if pipe is not None:  # the only exchange of the path: results to rank 0 over xGMI
+            if backend != "nccl":  # rehearsal only: gloo's gathers of GPU tensors hang behind a running kernel
+                torch.cuda.synchronize()
+            pipe.submit(slot, {name: out_buf[name] for name in ("J", "iters", "status", "xs", "us")})
         return res
 
     def barrier():
+        if pipe is not None:
+            pipe.drain()  # orders the stream behind every gather issued so far
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -256,6 +280,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    out_buf = out_sets[(n_steps[0] - 1) % n_sets]
     iters = out_buf["iters"].cpu().numpy().astype(np.int64)
     status = out_buf["status"].cpu().numpy()
     J = out_buf["J"].cpu().numpy()

@@ -68,3 +68,55 @@ def solve_sharded(local_solve, x0, us_init, dst=0, group=None, keys=("xs", "us",
     for key in keys:
         gathered[key] = gather_to_root(res[key], sizes, dst=dst, group=group)
     return res, (gathered if rank == dst else None)
+
+
+class GatherPipeline(object):
+    """Gathers of successive solves that overlap the next solve.
+
+    A batch job that solves one batch after another does not have to wait for the results of
+    batch i to reach the root before it starts batch i+1: the collective runs on the backend's
+    own stream (RCCL) or thread (gloo) while the device computes.  The caller alternates between
+    ``depth`` sets of result tensors; ``submit`` starts the gather of one set, ``reclaim`` must be
+    called before a set is overwritten, ``drain`` before the results are read or a timed region
+    ends.  Slices must have equal sizes (the weak-scaling layout: every rank owns as many
+    problems); the root receives into preallocated [world, n, ...] tensors, one per set and key.
+    """
+
+    def __init__(self, depth=2, dst=0, group=None):
+        import torch.distributed as dist
+        self.depth, self.dst, self.group = depth, dst, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.pending = [[] for _ in range(depth)]  # outstanding work handles per set
+        self.recv = [dict() for _ in range(depth)]  # root: key -> [world, n, ...] tensor
+
+    def submit(self, slot, tensors):
+        """Start gathering the dict ``tensors`` (key -> [n, ...], contiguous) of set ``slot``."""
+        import torch
+        import torch.distributed as dist
+        assert not self.pending[slot], "reclaim() the set before submitting it again"
+        for key, t in tensors.items():
+            assert t.is_contiguous()
+            parts = None
+            if self.rank == self.dst:
+                buf = self.recv[slot].get(key)
+                if buf is None or buf.shape[1:] != t.shape or buf.dtype != t.dtype:
+                    buf = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                    self.recv[slot][key] = buf
+                parts = list(buf.unbind(0))
+            self.pending[slot].append(dist.gather(t, parts, dst=self.dst, group=self.group, async_op=True))
+
+    def reclaim(self, slot):
+        """Order everything issued afterwards (on the current stream) behind the gathers of the set."""
+        for w in self.pending[slot]:
+            w.wait()
+        self.pending[slot] = []
+
+    def drain(self):
+        for slot in range(self.depth):
+            self.reclaim(slot)
+
+    def result(self, slot, key):
+        """Root, after reclaim/drain: the gathered [world * n, ...] tensor of the set (a view)."""
+        buf = self.recv[slot][key]
+        return buf.reshape((-1,) + tuple(buf.shape[2:]))

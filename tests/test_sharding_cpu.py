@@ -67,3 +67,43 @@ def test_two_rank_gloo_solve_equals_unsharded(tmp_path, B):
     ref = co.solve(co.cartpole_model(T=T), co.Opts(max_iter=15), x0, us0, trace=False)
     for k in ("xs", "us", "J", "iters", "status"):
         assert g[k].shape == ref[k].shape and np.array_equal(g[k], ref[k]), k
+
+
+def _pipeline_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = sharding.GatherPipeline(depth=2, dst=0)
+        sets = [dict(J=torch.empty(5, dtype=torch.float64), it=torch.empty((5, 3), dtype=torch.int32))
+                for _ in range(2)]
+        seen = []
+        for step in range(5):
+            slot = step % 2
+            pipe.reclaim(slot)
+            if rank == 0 and step >= 2:  # the set's previous contents have arrived and are still intact
+                seen.append((step - 2, pipe.result(slot, "J").clone(), pipe.result(slot, "it").clone()))
+            sets[slot]["J"].copy_(torch.arange(5, dtype=torch.float64) + 100 * step + 10 * rank)
+            sets[slot]["it"].fill_(1000 * step + rank)
+            pipe.submit(slot, sets[slot])
+        pipe.drain()
+        if rank == 0:
+            for step in (3, 4):
+                seen.append((step, pipe.result(step % 2, "J").clone(), pipe.result(step % 2, "it").clone()))
+            for step, J, it in seen:
+                want_J = torch.cat([torch.arange(5, dtype=torch.float64) + 100 * step + 10 * r for r in range(world)])
+                want_it = torch.cat([torch.full((5, 3), 1000 * step + r, dtype=torch.int32) for r in range(world)])
+                assert torch.equal(J, want_J) and torch.equal(it, want_it), step
+            assert sorted(s for s, _, _ in seen) == [0, 1, 2, 3, 4]
+            open(os.path.join(out_dir, "ok"), "w").close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_pipelined_gathers_deliver_every_set(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
