@@ -1126,20 +1126,15 @@ struct LSolveBuf {
     double *xs1, *us1, *k1, *K1; // second copies (workspace); the first copies are the caller's arrays
 };
 
-// iLQR.update_u (ilqr_core.py:241-399), one problem per wavefront.
+// iLQR.update_u (ilqr_core.py:241-399) for problem b, run by one wavefront.
 template <bool PATH>
-__global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int64_t B, const double* x0,
-                                                     const double* us_init, double* delta_io, double* k0, double* K0,
-                                                     double* xs0, double* us0, LSolveBuf W, double* J_out,
-                                                     double* mu_out, int32_t* iters_out, int32_t* status_out,
-                                                     ilqr_trace tr)
+__device__ __forceinline__ void large_solve_one(const LargeP& P, const LSolveOpts& O, BlockMem& M, WaveMem& S,
+                                                const int64_t b, const int64_t B, const double* x0,
+                                                const double* us_init, double* delta_io, double* k0, double* K0,
+                                                double* xs0, double* us0, const LSolveBuf& W, double* J_out,
+                                                double* mu_out, int32_t* iters_out, int32_t* status_out,
+                                                const ilqr_trace& tr)
 {
-    __shared__ BlockMem M;
-    block_init(M, P, O.qp.step_dec);
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B)
-        return;
-    WaveMem& S = M.wv[threadIdx.x >> 6];
     const int T = P.T;
     const LaneId L = lane_id();
     const int lane = threadIdx.x & 63;
@@ -1275,6 +1270,34 @@ __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int
         mu_out[b] = mu;
         iters_out[b] = iters;
         status_out[b] = status;
+    }
+    wave_sync(); // the wave's LDS region is reused by its next problem
+}
+
+// One problem per wavefront, taken from a queue: a wavefront that has finished its problem fetches the index
+// of the next unsolved one from a counter in device memory (zeroed by the host before the launch) and leaves
+// when the counter has passed B.  Iteration counts differ widely between problems (mean 11, maximum 116 on
+// the synthetic workload), so a workgroup of four fixed problems would hold its CU until the slowest of the
+// four has ended.  Which wavefront solves which problem has no influence on the results.
+template <bool PATH>
+__global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int64_t B, const double* x0,
+                                                     const double* us_init, double* delta_io, double* k0, double* K0,
+                                                     double* xs0, double* us0, LSolveBuf W, int* queue, double* J_out,
+                                                     double* mu_out, int32_t* iters_out, int32_t* status_out,
+                                                     ilqr_trace tr)
+{
+    __shared__ BlockMem M;
+    block_init(M, P, O.qp.step_dec);
+    WaveMem& S = M.wv[threadIdx.x >> 6];
+    for (;;) {
+        int next = 0;
+        if ((threadIdx.x & 63) == 0)
+            next = atomicAdd(queue, 1);
+        const int64_t b = __builtin_amdgcn_readfirstlane(next);
+        if (b >= B)
+            break;
+        large_solve_one<PATH>(P, O, M, S, b, B, x0, us_init, delta_io, k0, K0, xs0, us0, W, J_out, mu_out, iters_out,
+                              status_out, tr);
     }
 }
 
@@ -1427,7 +1450,8 @@ size_t ilqr_large_workspace_bytes(const ilqr_large_model* model, int64_t B)
     if (large_check(model) != ILQR_OK || B < 1)
         return 0;
     size_t T = (size_t)model->T;
-    return (size_t)B * sizeof(double) * ((T + 1) * LN + T * LM + T * LM + T * LM * LN);
+    // second copies of xs, us, k, K and (256 bytes, at the end) the problem queue's counter
+    return (size_t)B * sizeof(double) * ((T + 1) * LN + T * LM + T * LM + T * LM * LN) + 256;
 }
 
 int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
@@ -1468,17 +1492,31 @@ int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opt
     W.k1 = p;
     p += (size_t)B * T * LM;
     W.K1 = p;
+    p += (size_t)B * T * LM * LN;
+    int* queue = reinterpret_cast<int*>(p);
+    if (B > 0x7fffffff - 4096)
+        return ILQR_ERR_ARG; // the queue's counter is a 32-bit integer
+    hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), ls(stream));
+    if (e != hipSuccess)
+        return lrc(e);
+    // one workgroup (4 wavefronts, 123 KB of LDS) per CU is resident at a time; more would only start to
+    // find the queue empty
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
+        n_cu = 256;
+    const int64_t groups = (B + 3) / 4 < n_cu ? (B + 3) / 4 : n_cu;
     ilqr_trace tr;
     if (trace)
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
     if (model->cost_kind == ILQR_COST_PATH_QR) {
-        hipLaunchKernelGGL(k_large_solve<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), O, B, x0, us_init,
-                           delta, k, K, xs, us, W, J, mu, iters, status, tr);
+        hipLaunchKernelGGL(k_large_solve<true>, dim3((unsigned)groups), dim3(256), 0, ls(stream), large_fill(model), O, B,
+                           x0, us_init, delta, k, K, xs, us, W, queue, J, mu, iters, status, tr);
     } else {
-        hipLaunchKernelGGL(k_large_solve<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), O, B, x0, us_init,
-                           delta, k, K, xs, us, W, J, mu, iters, status, tr);
+        hipLaunchKernelGGL(k_large_solve<false>, dim3((unsigned)groups), dim3(256), 0, ls(stream), large_fill(model), O, B,
+                           x0, us_init, delta, k, K, xs, us, W, queue, J, mu, iters, status, tr);
     }
     return lrc(hipGetLastError());
 }

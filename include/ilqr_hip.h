@@ -253,7 +253,9 @@ int ilqr_large_forward_ls(const ilqr_large_model* model, int64_t B, int32_t n_al
  * part 1, boxQP and gains, matrix part 2), T, and a breakdown of the second phase.  NULL switches it off.  Synchronous. */
 int ilqr_large_debug_profile(void* device_buffer);
 
-/* iLQR.update_u (ilqr_core.py:241-399), arguments as ilqr_solve_batched. */
+/* iLQR.update_u (ilqr_core.py:241-399), arguments as ilqr_solve_batched.  One problem per wavefront; the
+ * wavefronts of at most one workgroup per CU take problems from a queue (a counter at the end of the
+ * workspace, zeroed on the stream before the launch), so a long solve does not hold up its neighbours. */
 size_t ilqr_large_workspace_bytes(const ilqr_large_model* model, int64_t B);
 int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
                              const double* us_init, double* delta, double* k, double* K, double* xs, double* us,

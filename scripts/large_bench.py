@@ -43,7 +43,7 @@ def main():
     t_roll, (xs, J) = timed(lambda: _hip.large_rollout_cost(M, x0, us))
     mu = torch.ones(B, dtype=torch.float64, device=dev)
     t_bw, bw = timed(lambda: _hip.large_backward(M, O, xs, us, mu, want_masks=False))
-    al = co.line_search_alphas(30)
+    al = 1.1 ** (-np.arange(30.0) ** 2)  # ilqr_core.py:267
     t_fw16, _ = timed(lambda: _hip.large_forward_ls(M, al[:16], xs, us, bw["k"], bw["K"]))
     t_solve, out = timed(lambda: _hip.large_solve(M, O, x0, us), reps=2)
     iters = out["iters"].cpu().numpy().astype(np.int64)
@@ -59,14 +59,20 @@ def main():
     print("solve               %8.3f ms  -> %.0f solves/s, %.1f iterations/solve (max %d), converged %.1f %%, "
           "%.2f ms per iteration of the batch" % (t_solve * 1e3, B / t_solve, iters.mean(), iters.max(),
                                                   100.0 * np.mean(status == 1), t_solve * 1e3 / iters.max()))
-    # CPU port on the host cores, bounded sample
-    n_cpu = min(B, 64)
-    thr = min(16, os.cpu_count() or 1)
-    t0 = time.perf_counter()
-    ref = co.solve(Mo, co.Opts(), x0_h[:n_cpu], us_h[:n_cpu], nthreads=thr, trace=False)
-    t_cpu = time.perf_counter() - t0
-    print("CPU port (%d threads, %d problems): %.2f solves/s; first %d problems equal: %s"
-          % (thr, n_cpu, n_cpu / t_cpu, n_cpu, bool(np.array_equal(ref["us"], out["us"][:n_cpu].cpu().numpy()))))
+    # How far the launch is from a perfectly balanced one: a problem takes iters x (time per iteration); wavefronts
+    # take problems from a queue in index order (list scheduling on 1024 wavefronts).
+    import heapq
+
+    def makespan(jobs, slots):
+        heap = [0.0] * slots
+        for j in jobs:
+            heapq.heappush(heap, heapq.heappop(heap) + j)
+        return max(heap)
+    per_it = t_solve / makespan(iters, 1024)
+    print("list-scheduling model: %.2f ms per iteration of one problem; if four fixed problems shared a workgroup: %.0f ms; "
+          "as launched (queue): %.0f ms; perfectly divisible: %.0f ms; longest problem alone: %.0f ms"
+          % (per_it * 1e3, per_it * makespan(iters[:B // 4 * 4].reshape(-1, 4).max(1), 256) * 1e3, t_solve * 1e3,
+             per_it * iters.sum() / 1024 * 1e3, per_it * iters.max() * 1e3))
 
 
 if __name__ == "__main__":

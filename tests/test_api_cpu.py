@@ -54,7 +54,7 @@ def test_argument_checks_need_no_gpu():
     assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -1
     for name, _ in _hip.LargeModelC._fields_[6:]:
         setattr(L, name, 4096)  # never dereferenced: the checks below fail first
-    assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == 10 * 8 * (21 * 32 + 20 * 8 + 20 * 8 + 20 * 8 * 32)
+    assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == 10 * 8 * (21 * 32 + 20 * 8 + 20 * 8 + 20 * 8 * 32) + 256
     assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(0), None, None, None, None, None) == -1
     L.n = 16
     assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -2
