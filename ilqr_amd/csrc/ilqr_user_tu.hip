@@ -933,140 +933,223 @@ __device__ __forceinline__ UWork utile(double* ws, int64_t tile, int64_t T)
     return W;
 }
 
-// iLQR.update_u (ilqr_core.py:241-399), every lane its own problem, serial first-hit line search.
+constexpr int GLS_PASS = 8;  // problems per cooperative line-search pass
+constexpr int GLS_MAXA = 32; // largest alpha schedule
+
+// iLQR.update_u (ilqr_core.py:241-399), every lane its own problem.
+// Line search (:301-313) as in the single-control kernel: every lane rolls out alpha_0 for its own problem;
+// the problems that need more hand their remaining candidates to the whole wave (lane = one (problem, alpha)
+// pair, costs into LDS) and then scan the costs in the reference's order.  A rollout is a pure function of
+// (problem, alpha), so decisions and numbers are those of the serial loop; a rejected iteration costs a few
+// rollout times instead of up to 30.
 __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg, SolveOptsP O, GBounds bd, int T, int64_t B,
                                                      double* ws, const double* x0, const double* us_init,
                                                      double* delta_io, double* k_io, double* K_io, double* xs_out,
                                                      double* us_out, double* J_out, double* mu_out,
                                                      int32_t* iters_out, int32_t* status_out, ilqr_trace tr)
 {
-    // one or four wavefronts per workgroup (the host chooses)
-    const int lane = threadIdx.x & 63;
+    // one or four wavefronts per workgroup (the host chooses); a wave only talks to itself
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // the cost matrices are read from LDS (wave-uniform addresses) instead of occupying scalar registers
     __shared__ GCost s_cost;
+    __shared__ double s_alpha[GLS_MAXA];
+    __shared__ double s_J_all[UWG][GLS_PASS][GLS_MAXA];
+    __shared__ int s_lane_all[UWG][GLS_PASS], s_cur_all[UWG][GLS_PASS], s_gcur_all[UWG][GLS_PASS];
+    double(&s_J)[GLS_PASS][GLS_MAXA] = s_J_all[wv];
+    int(&s_lane)[GLS_PASS] = s_lane_all[wv];
+    int(&s_cur)[GLS_PASS] = s_cur_all[wv];
+    int(&s_gcur)[GLS_PASS] = s_gcur_all[wv];
     if (threadIdx.x == 0)
         s_cost = C_arg;
+    if (threadIdx.x < GLS_MAXA)
+        s_alpha[threadIdx.x] = O.alphas[threadIdx.x];
     const GCost& C = s_cost;
     __syncthreads();
     // problems per wavefront: the first O.lanes_per_wave columns of the wave's 64-column tile are in use
-    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     const int64_t b = tile * O.lanes_per_wave + lane;
-    if (lane >= O.lanes_per_wave || b >= B)
-        return;
+    const bool valid = lane < O.lanes_per_wave && b < B;
     const UWork W = utile(ws, tile, T);
     const int64_t bl = lane;
 #define XS(i) ((i) ? W.xs1 : W.xs0)
 #define US(i) ((i) ? W.us1 : W.us0)
 #define KF(i) ((i) ? W.k1 : W.k0)
 #define KG(i) ((i) ? W.K1 : W.K0)
-    for (int i = 0; i < UN; ++i)
-        W.xs0[(int64_t)i * 64 + bl] = x0[b * UN + i];
-    for (int t = 0; t < T; ++t) {
-        for (int j = 0; j < UM; ++j) {
-            W.us0[((int64_t)t * UM + j) * 64 + bl] = us_init[(b * T + t) * UM + j];
-            W.k0[((int64_t)t * UM + j) * 64 + bl] = k_io[(b * T + t) * UM + j];
-        }
-        for (int i = 0; i < UM * UN; ++i)
-            W.K0[((int64_t)t * UM * UN + i) * 64 + bl] = K_io[(b * T + t) * UM * UN + i];
-    }
     const QPOptsP& QO = O.qp;
     int cur = 0, gcur = 0;
-    double mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
-    double delta = delta_io[b];
-    // initial rollout and cost (:269-271)
-    double J = gforward(P, C, T, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
+    double mu = 1.0, delta = 2.0, J = 0.0;
+    if (valid) {
+        for (int i = 0; i < UN; ++i)
+            W.xs0[(int64_t)i * 64 + bl] = x0[b * UN + i];
+        for (int t = 0; t < T; ++t) {
+            for (int j = 0; j < UM; ++j) {
+                W.us0[((int64_t)t * UM + j) * 64 + bl] = us_init[(b * T + t) * UM + j];
+                W.k0[((int64_t)t * UM + j) * 64 + bl] = k_io[(b * T + t) * UM + j];
+            }
+            for (int i = 0; i < UM * UN; ++i)
+                W.K0[((int64_t)t * UM * UN + i) * 64 + bl] = K_io[(b * T + t) * UM * UN + i];
+        }
+        mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
+        delta = delta_io[b];
+        // initial rollout and cost (:269-271)
+        J = gforward(P, C, T, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
+    }
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
     int status = ILQR_RAN_OUT, iters = 0;
+    bool running = valid && O.max_iter > 0;
+    const int n_more = O.n_alpha - 1; // candidates after alpha_0
     for (int it = 0; it < O.max_iter; ++it) {
+        if (__ballot(running) == 0ull)
+            break;
         GAcc S;
         int stopped_at = -1;
         S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
-        // backward pass with the LinAlgError retry loop (:287-299)
-        for (;;) {
-            int gnew = gcur ^ 1;
-            int rc = gbackward(P, C, QO, bd, T, bl, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S, stopped_at);
-            if (rc != BW_LINALG) {
-                gcur = gnew;
-                dJ1 = S.dJ1;
-                dJ2 = S.dJ2;
-                break;
-            }
-            delta = fmax(delta, 1.0) * O.delta0;
-            mu = fmax(O.mu_min, mu * delta);
-            if (O.mu_max != 0.0 && mu >= O.mu_max)
-                break;
-        }
-        // line search: the serial first-hit scan (:301-313)
         int accepted = 0, j = 0;
         double Jnew = 0.0;
         const int nxt = cur ^ 1;
-        for (j = 0; j < O.n_alpha; ++j) {
-            double alpha = O.alphas[j];
-            Jnew = gforward(P, C, T, bl, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
-            double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
-            if (expected <= 0.0)
-                break;
-            if ((J - Jnew) / expected > O.scale) {
-                actual = J - Jnew;
-                accepted = 1;
-                break;
+        bool need = false; // the serial loop would go on to alpha_1
+        if (running) {
+            // backward pass with the LinAlgError retry loop (:287-299)
+            for (;;) {
+                int gnew = gcur ^ 1;
+                int rc = gbackward(P, C, QO, bd, T, bl, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S, stopped_at);
+                if (rc != BW_LINALG) {
+                    gcur = gnew;
+                    dJ1 = S.dJ1;
+                    dJ2 = S.dJ2;
+                    break;
+                }
+                delta = fmax(delta, 1.0) * O.delta0;
+                mu = fmax(O.mu_min, mu * delta);
+                if (O.mu_max != 0.0 && mu >= O.mu_max)
+                    break;
+            }
+            // line search, alpha_0 (:301-313)
+            if (O.n_alpha > 0) {
+                double alpha = s_alpha[0];
+                Jnew = gforward(P, C, T, bl, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
+                double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+                if (expected <= 0.0) {
+                    // reject the whole iteration
+                } else if ((J - Jnew) / expected > O.scale) {
+                    actual = J - Jnew;
+                    accepted = 1;
+                } else {
+                    need = n_more > 0;
+                    j = need ? 1 : O.n_alpha;
+                }
             }
         }
-        bool stop = false;
-        int converged = 0;
-        if (accepted) {
-            delta = fmin(1.0, delta) / O.delta0;
-            mu = mu * delta;
-            if (mu <= O.mu_min)
-                mu = 0.0;
-            J = Jnew;
-            cur = nxt;
-            if (actual < O.tol)
-                converged = 1;
-        } else {
-            delta = fmax(delta, 1.0) * O.delta0;
-            mu = fmax(O.mu_min, mu * delta);
-            if (O.mu_max != 0.0 && mu >= O.mu_max) {
-                status = ILQR_MU_MAX;
-                stop = true;
+        // remaining alphas of the problems that need them, GLS_PASS problems per pass
+        // (helper lanes read gains another lane of this wave has just stored)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        unsigned long long mask = __ballot(need);
+        bool redo = false; // accepted at some alpha_j, j >= 1: its trajectory still has to be written
+        while (mask != 0ull) {
+            int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            bool mine = need && rank < GLS_PASS;
+            if (mine) {
+                s_lane[rank] = lane;
+                s_cur[rank] = cur;
+                s_gcur[rank] = gcur;
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int np = __popcll(mask);
+            np = np < GLS_PASS ? np : GLS_PASS;
+            int nc = np * n_more;
+            for (int q0 = 0; q0 < nc; q0 += 64) {
+                int q = q0 + lane;
+                if (q < nc) {
+                    int fi = q / n_more, jj = 1 + q % n_more;
+                    int64_t pb = s_lane[fi];
+                    int pc = s_cur[fi], pg = s_gcur[fi];
+                    s_J[fi][jj] = gforward(P, C, T, pb, XS(pc), US(pc), KF(pg), KG(pg), s_alpha[jj], XS(pc), nullptr, nullptr);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                // the reference's loop from alpha_1 on, on the tabulated costs
+                for (j = 1; j < O.n_alpha; ++j) {
+                    double alpha = s_alpha[j];
+                    Jnew = s_J[rank][j];
+                    double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+                    if (expected <= 0.0) {
+                        break;
+                    } else if ((J - Jnew) / expected > O.scale) {
+                        actual = J - Jnew;
+                        accepted = 1;
+                        redo = true;
+                        break;
+                    }
+                }
+                need = false;
+            }
+            __builtin_amdgcn_wave_barrier();
+            mask = __ballot(need);
         }
-        int64_t to = (int64_t)it * B + b;
-        if (tr.J) tr.J[to] = J;
-        if (tr.accepted) tr.accepted[to] = accepted;
-        if (tr.alpha_idx) tr.alpha_idx[to] = j;
-        if (tr.mu) tr.mu[to] = mu;
-        if (tr.delta) tr.delta[to] = delta;
-        if (tr.qp_iter) tr.qp_iter[to] = S.qp_iter;
-        if (tr.qp_backtrack) tr.qp_backtrack[to] = S.qp_backtrack;
-        if (tr.n_clamped) tr.n_clamped[to] = S.n_clamped;
-        if (tr.stopped_at) tr.stopped_at[to] = stopped_at;
-        iters = it + 1;
-        if (converged)
-            status = ILQR_CONVERGED;
-        if (stop || converged)
-            break;
-    }
-    const double* xf = XS(cur);
-    const double* uf = US(cur);
-    const double* kf = KF(gcur);
-    const double* Kf = KG(gcur);
-    for (int t = 0; t <= T; ++t)
-        for (int i = 0; i < UN; ++i)
-            xs_out[(b * (T + 1) + t) * UN + i] = xf[((int64_t)t * UN + i) * 64 + bl];
-    for (int t = 0; t < T; ++t) {
-        for (int j = 0; j < UM; ++j) {
-            us_out[(b * T + t) * UM + j] = uf[((int64_t)t * UM + j) * 64 + bl];
-            k_io[(b * T + t) * UM + j] = kf[((int64_t)t * UM + j) * 64 + bl];
+        if (redo) // the accepted candidate's states and controls (same arithmetic, same bits)
+            Jnew = gforward(P, C, T, bl, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(cur), XS(nxt), US(nxt));
+        if (running) {
+            bool stop = false;
+            int converged = 0;
+            if (accepted) {
+                delta = fmin(1.0, delta) / O.delta0;
+                mu = mu * delta;
+                if (mu <= O.mu_min)
+                    mu = 0.0;
+                J = Jnew;
+                cur = nxt;
+                if (actual < O.tol)
+                    converged = 1;
+            } else {
+                delta = fmax(delta, 1.0) * O.delta0;
+                mu = fmax(O.mu_min, mu * delta);
+                if (O.mu_max != 0.0 && mu >= O.mu_max) {
+                    status = ILQR_MU_MAX;
+                    stop = true;
+                }
+            }
+            int64_t to = (int64_t)it * B + b;
+            if (tr.J) tr.J[to] = J;
+            if (tr.accepted) tr.accepted[to] = accepted;
+            if (tr.alpha_idx) tr.alpha_idx[to] = j;
+            if (tr.mu) tr.mu[to] = mu;
+            if (tr.delta) tr.delta[to] = delta;
+            if (tr.qp_iter) tr.qp_iter[to] = S.qp_iter;
+            if (tr.qp_backtrack) tr.qp_backtrack[to] = S.qp_backtrack;
+            if (tr.n_clamped) tr.n_clamped[to] = S.n_clamped;
+            if (tr.stopped_at) tr.stopped_at[to] = stopped_at;
+            iters = it + 1;
+            if (converged)
+                status = ILQR_CONVERGED;
+            if (stop || converged)
+                running = false;
         }
-        for (int i = 0; i < UM * UN; ++i)
-            K_io[(b * T + t) * UM * UN + i] = Kf[((int64_t)t * UM * UN + i) * 64 + bl];
     }
-    delta_io[b] = delta;
-    J_out[b] = J;
-    mu_out[b] = mu;
-    iters_out[b] = iters;
-    status_out[b] = status;
+    if (valid) {
+        const double* xf = XS(cur);
+        const double* uf = US(cur);
+        const double* kf = KF(gcur);
+        const double* Kf = KG(gcur);
+        for (int t = 0; t <= T; ++t)
+            for (int i = 0; i < UN; ++i)
+                xs_out[(b * (T + 1) + t) * UN + i] = xf[((int64_t)t * UN + i) * 64 + bl];
+        for (int t = 0; t < T; ++t) {
+            for (int j2 = 0; j2 < UM; ++j2) {
+                us_out[(b * T + t) * UM + j2] = uf[((int64_t)t * UM + j2) * 64 + bl];
+                k_io[(b * T + t) * UM + j2] = kf[((int64_t)t * UM + j2) * 64 + bl];
+            }
+            for (int i = 0; i < UM * UN; ++i)
+                K_io[(b * T + t) * UM * UN + i] = Kf[((int64_t)t * UM * UN + i) * 64 + bl];
+        }
+        delta_io[b] = delta;
+        J_out[b] = J;
+        mu_out[b] = mu;
+        iters_out[b] = iters;
+        status_out[b] = status;
+    }
 #undef XS
 #undef US
 #undef KF

@@ -13,7 +13,7 @@
  * (or, instead of ilqr_user_jac,  #define ILQR_USER_FD : forward-difference Jacobian as the
  * reference's FiniteDifferenceDynamics, see ilqr_user_fd.h).  With  #define ILQR_USER_M <2..4>
  * the model has that many controls and both functions take  const double* u  (fu: [N][M]
- * row-major); such models run on a general per-lane path (dense boxQP, serial line search).
+ * row-major); such models run on a general per-lane path (dense boxQP; line search as for one control).
  * The functions
  * may use ilqr_sincos(x, &s, &c), ilqr_atan2(y, x), ilqr_sqrt(x) and plain arithmetic;
  * ilqr_amd/csrc/ilqr_user_tu.hip is compiled around it into one shared library per model
