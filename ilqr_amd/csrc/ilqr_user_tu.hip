@@ -1186,7 +1186,7 @@ int ulanes(int64_t B)
 }
 // Wavefronts per workgroup.  The single-control kernel runs 3-5 % faster with four waves on one CU than
 // with one wave on each of four CUs (as the built-in cart-pole kernel does).  The multi-control kernel,
-// which spills to scratch memory and leans on the CU's vector cache, is 18 % slower that way while CUs
+// which spills to scratch memory and leans on the CU's vector cache, is 10-18 % slower that way while CUs
 // are free; once every CU holds four waves anyway the two shapes measure alike.
 int uwaves_per_group(int64_t nwaves)
 {

@@ -569,3 +569,32 @@ def test_c_level_chunked_solve_equals_single_launch(hip, B, chunk):
                             delta=chunked["delta"], k=chunked["k"], K=chunked["K"])
     for key in ("xs", "us", "J", "iters", "status", "K"):
         assert torch.equal(one2[key], ch2[key]), key
+
+
+def test_every_launch_shape_gives_the_same_bits(hip):
+    """Problems per wavefront and wavefronts per workgroup only change the lane -> problem map."""
+    import os
+    Mo = co.cartpole_model(T=40)
+    M = hip_model(hip, Mo)
+    B = 333  # ragged: the last wavefront and the last workspace tile are partly empty in every shape
+    x0, us0 = co.cartpole_batch(B, T=Mo.T, seed_x=91, seed_u=92)
+    ref = co.solve(Mo, co.Opts(max_iter=40), x0, us0, nthreads=8, trace=False)
+    saved = {k: os.environ.get(k) for k in ("ILQR_SOLVE_LPW", "ILQR_SOLVE_BLOCK")}
+    try:
+        for lpw, blk in ((None, None), (64, 64), (64, 128), (64, 256), (32, 128), (32, 256), (16, 256)):
+            for key, val in (("ILQR_SOLVE_LPW", lpw), ("ILQR_SOLVE_BLOCK", blk)):
+                if val is None:
+                    os.environ.pop(key, None)
+                else:
+                    os.environ[key] = str(val)
+            out = hip.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0))
+            for key in ("xs", "us", "J", "k", "K", "mu", "delta"):
+                assert eq(out[key].cpu().numpy(), ref[key]), (lpw, blk, key)
+            assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"]), (lpw, blk)
+            assert np.array_equal(out["status"].cpu().numpy(), ref["status"]), (lpw, blk)
+    finally:
+        for key, val in saved.items():
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
