@@ -170,3 +170,32 @@ class PathQRCost(Cost):
         if terminal:
             return np.zeros_like(self.R)
         return self._R_plus_R_T
+
+
+class _CallbackCost(Cost):
+    """Costs defined by Python callables (ilqr/ilqr_cost.py:93-483) are evaluated once per time step
+    through the interpreter, which cannot happen inside a kernel; the device solver evaluates the
+    quadratic families above (``QRCost``, ``PathQRCost``) in registers.  The names are kept so that
+    code importing them fails with an explanation instead of an ImportError."""
+
+    _what = "a cost given as Python callables"
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(
+            "%s is not available on the GPU path: the solve kernels evaluate QRCost / PathQRCost only "
+            "(a tracking problem with time-varying goals is a PathQRCost)." % self._what)
+
+    def l(self, x, u, i, terminal=False):
+        raise NotImplementedError
+
+    l_x = l_u = l_xx = l_ux = l_uu = l
+
+
+class FiniteDifferenceCost(_CallbackCost):
+    """ilqr/ilqr_cost.py:93-205."""
+    _what = "FiniteDifferenceCost (numerical derivatives of a Python cost function)"
+
+
+class AutogradCost(_CallbackCost):
+    """ilqr/ilqr_cost.py:207-483."""
+    _what = "AutogradCost (symbolic derivatives of a Theano cost expression)"

@@ -236,3 +236,7 @@ def test_finite_difference_dynamics_mirror():
         iLQR(d, QRCost(np.eye(2), np.eye(1)), 5)
     with pytest.raises(NotImplementedError):
         AutogradDynamics(None, None, None)
+    from ilqr_amd.ilqr_cost import AutogradCost, FiniteDifferenceCost
+    for callback_cost in (AutogradCost, FiniteDifferenceCost):  # importable, refused with an explanation
+        with pytest.raises(NotImplementedError, match="QRCost / PathQRCost"):
+            callback_cost(None, None, 2, 1)
