@@ -69,7 +69,7 @@ EXPORTS = (
     "ilqr_solve_chunked_workspace_bytes", "ilqr_solve_batched_chunked",
     "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
     "ilqr_large_rollout_cost", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
-    "ilqr_large_solve_batched", "ilqr_large_debug_profile",
+    "ilqr_large_solve_batched", "ilqr_large_debug_profile", "ilqr_cartpole_mpc_advance",
 )
 
 _lib = None
@@ -379,6 +379,22 @@ def plant_step(st, u, gravity=9.8, masscart=1.0, masspole=0.1, length=0.5, tau=0
     check(lib().ilqr_cartpole_plant_step(C.c_int64(B), par.ctypes.data_as(_dp), _ptr(_req(st, torch.float64)),
                                          _ptr(_req(u.reshape(B), torch.float64)), _ptr(out), _stream()))
     return out
+
+
+def mpc_advance(st, us_solved, us_seed, u_applied, x0_aug, gravity=9.8, masscart=1.0, masspole=0.1, length=0.5,
+                tau=0.05):
+    """Plant step with us_solved[:, 0] (in place on st), augmented state and shifted control seed for the next
+    solve, one launch.  All arguments are contiguous fp64 device tensors; us_seed must not be us_solved."""
+    import torch
+    B, N = us_solved.shape[0], us_solved.shape[1]
+    for t in (st, us_solved, us_seed, u_applied, x0_aug):
+        if t.dtype != torch.float64 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("mpc_advance: contiguous fp64 device tensors expected")
+    if st.shape != (B, 4) or us_seed.numel() != B * N or u_applied.numel() != B or x0_aug.shape != (B, 5):
+        raise ValueError("mpc_advance: shapes")
+    par = _host([gravity, masscart, masspole, length, tau], (5,))
+    check(lib().ilqr_cartpole_mpc_advance(C.c_int64(B), C.c_int64(N), par.ctypes.data_as(_dp), _ptr(st),
+                                          _ptr(us_solved), _ptr(us_seed), _ptr(u_applied), _ptr(x0_aug), _stream()))
 
 
 def detmath(a, b):

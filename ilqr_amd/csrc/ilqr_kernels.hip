@@ -79,18 +79,6 @@ __global__ __launch_bounds__(256) void k_pack(const double* __restrict__ src, do
     }
 }
 
-// ref [B, Rs] -> the first Rs rows of a wave-tiled array with Rd rows per tile.
-__global__ __launch_bounds__(256) void k_pack_rows(const double* __restrict__ src, double* __restrict__ dst,
-                                                   int64_t B, int64_t Rs, int64_t Rd)
-{
-    int64_t nblk = (int64_t)gridDim.x * gridDim.y;
-    int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-    for (; i < B * Rs; i += nblk * 256) {
-        int64_t b = i / Rs, r = i % Rs;
-        dst[bm_index(r, b, Rd, 0)] = src[i];
-    }
-}
-
 // bm -> ref [B, R]; with sel != nullptr problem b reads srcB when sel[b] != 0.
 __global__ __launch_bounds__(256) void k_unpack(const double* __restrict__ srcA,
                                                 const double* __restrict__ srcB,
@@ -108,6 +96,99 @@ __global__ __launch_bounds__(256) void k_unpack(const double* __restrict__ srcA,
     for (int j = ty; j < 64; j += 4) {
         int64_t r = r0 + j;
         tile[j][tx] = (r < R && bl < B) ? src[bm_index(r, bl, R, ld)] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        int64_t b = b0 + j, r = r0 + tx;
+        if (b < B && r < R)
+            dst[b * R + r] = tile[tx][j];
+    }
+}
+
+// The four conversions on either side of a solve in one launch each (eight small launches cost a short
+// solve -- a closed-loop re-solve of 15 steps -- a sixth of its time).  Rows [y0[i], y0[i+1]) of the grid's
+// y dimension belong to job i.
+struct PackJobs {
+    const double* src[4];
+    double* dst[4];
+    int64_t R[4];  // rows of the source, [B, R]
+    int64_t Rd[4]; // rows per tile of the wave-tiled destination (>= R: the rows land at the top of the tile)
+    unsigned y0[5];
+};
+__global__ __launch_bounds__(256) void k_pack_jobs(PackJobs Jb, int64_t B)
+{
+    __shared__ double tile[64][65];
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        job += blockIdx.y >= Jb.y0[i] ? 1 : 0;
+    const double* __restrict__ src = Jb.src[0];
+    double* __restrict__ dst = Jb.dst[0];
+    int64_t R = Jb.R[0], Rd = Jb.Rd[0];
+    unsigned y0 = Jb.y0[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (job == i) {
+            src = Jb.src[i];
+            dst = Jb.dst[i];
+            R = Jb.R[i];
+            Rd = Jb.Rd[i];
+            y0 = Jb.y0[i];
+        }
+    int64_t b0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)(blockIdx.y - y0) * 64;
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        int64_t b = b0 + j, r = r0 + tx;
+        tile[j][tx] = (b < B && r < R) ? src[b * R + r] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        int64_t r = r0 + j, b = b0 + tx;
+        if (r < R && b < B)
+            dst[bm_index(r, b, Rd, 0)] = tile[tx][j];
+    }
+}
+
+struct UnpackJobs {
+    const double* srcA[4];
+    const double* srcB[4];
+    const int32_t* sel[4];
+    double* dst[4];
+    int64_t R[4];
+    unsigned y0[5];
+};
+__global__ __launch_bounds__(256) void k_unpack_jobs(UnpackJobs Jb, int64_t B)
+{
+    __shared__ double tile[64][65];
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        job += blockIdx.y >= Jb.y0[i] ? 1 : 0;
+    const double* srcA = Jb.srcA[0];
+    const double* srcB = Jb.srcB[0];
+    const int32_t* __restrict__ sel = Jb.sel[0];
+    double* __restrict__ dst = Jb.dst[0];
+    int64_t R = Jb.R[0];
+    unsigned y0 = Jb.y0[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (job == i) {
+            srcA = Jb.srcA[i];
+            srcB = Jb.srcB[i];
+            sel = Jb.sel[i];
+            dst = Jb.dst[i];
+            R = Jb.R[i];
+            y0 = Jb.y0[i];
+        }
+    int64_t b0 = (int64_t)blockIdx.x * 64, r0 = (int64_t)(blockIdx.y - y0) * 64;
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int64_t bl = b0 + tx;
+    const double* src = srcA;
+    if (bl < B && sel[bl] != 0)
+        src = srcB;
+    for (int j = ty; j < 64; j += 4) {
+        int64_t r = r0 + j;
+        tile[j][tx] = (r < R && bl < B) ? src[bm_index(r, bl, R, 0)] : 0.0;
     }
     __syncthreads();
     for (int j = ty; j < 64; j += 4) {
@@ -898,24 +979,63 @@ struct PlantP {
     double g, mc, mp, len, tau;
 };
 
+__device__ __forceinline__ void plant_step_one(const PlantP& p, const double (&s)[4], double force, double (&out)[4])
+{
+    double M = p.mp + p.mc, pml = p.mp * p.len;
+    double x = s[0], xd = s[1], th = s[2], thd = s[3];
+    double sn, cs;
+    det_sincos(th, sn, cs);
+    double temp = (force + pml * thd * thd * sn) / M;
+    double thacc = (p.g * sn - cs * temp) / (p.len * (4.0 / 3.0 - p.mp * cs * cs / M));
+    double xacc = temp - pml * thacc * cs / M;
+    out[0] = x + p.tau * xd;
+    out[1] = xd + p.tau * xacc;
+    out[2] = th + p.tau * thd;
+    out[3] = thd + p.tau * thacc;
+}
+
 __global__ __launch_bounds__(256) void k_plant_step(PlantP p, int64_t B, const double* __restrict__ st,
                                                     const double* __restrict__ u, double* __restrict__ out)
 {
     int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B)
         return;
-    double M = p.mp + p.mc, pml = p.mp * p.len;
-    double x = st[b * 4 + 0], xd = st[b * 4 + 1], th = st[b * 4 + 2], thd = st[b * 4 + 3];
-    double force = u[b];
+    double s[4] = {st[b * 4 + 0], st[b * 4 + 1], st[b * 4 + 2], st[b * 4 + 3]}, o[4];
+    plant_step_one(p, s, u[b], o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        out[b * 4 + i] = o[i];
+}
+
+// Everything between two solves of a closed loop (examples/cartpole_example_mpc.py:66-79 around
+// ilqr_core.py:451-465) in one launch: apply the first control of the solved sequence to the plant, augment
+// the new state for the next solve (cartpole.py:97-116), and seed the next solve with the sequence moved one
+// step along, its last control repeated (ilqr_core.py:463-465).  Same device functions, hence the same bits,
+// as the separate kernels.
+__global__ __launch_bounds__(256) void k_mpc_advance(PlantP p, int64_t B, int64_t N, double* __restrict__ st,
+                                                     const double* __restrict__ us_solved,
+                                                     double* __restrict__ us_seed, double* __restrict__ u_applied,
+                                                     double* __restrict__ x0_aug)
+{
+    int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B)
+        return;
+    double s[4] = {st[b * 4 + 0], st[b * 4 + 1], st[b * 4 + 2], st[b * 4 + 3]}, o[4];
+    double u0 = us_solved[b * N];
+    plant_step_one(p, s, u0, o);
+    u_applied[b] = u0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        st[b * 4 + i] = o[i];
     double sn, cs;
-    det_sincos(th, sn, cs);
-    double temp = (force + pml * thd * thd * sn) / M;
-    double thacc = (p.g * sn - cs * temp) / (p.len * (4.0 / 3.0 - p.mp * cs * cs / M));
-    double xacc = temp - pml * thacc * cs / M;
-    out[b * 4 + 0] = x + p.tau * xd;
-    out[b * 4 + 1] = xd + p.tau * xacc;
-    out[b * 4 + 2] = th + p.tau * thd;
-    out[b * 4 + 3] = thd + p.tau * thacc;
+    det_sincos(o[2], sn, cs);
+    x0_aug[b * 5 + 0] = o[0];
+    x0_aug[b * 5 + 1] = o[1];
+    x0_aug[b * 5 + 2] = sn;
+    x0_aug[b * 5 + 3] = cs;
+    x0_aug[b * 5 + 4] = o[3];
+    for (int64_t t = 0; t < N; ++t)
+        us_seed[b * N + t] = us_solved[b * N + (t + 1 < N ? t + 1 : N - 1)];
 }
 
 __global__ __launch_bounds__(256) void k_detmath(int64_t n, const double* a, const double* bb, double* s,
@@ -1287,13 +1407,24 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
     W.sel_traj = reinterpret_cast<int32_t*>(p);
     W.sel_gain = W.sel_traj + ld;
 
-    const int64_t tiled = 0; // ld = 0 selects the wave-tiled layout (bm_index)
-    // x0 goes to rows 0..4 of the (T+1)*5-row state array of each tile
-    hipLaunchKernelGGL(k_pack_rows, tile_grid(B, 5), dim3(256), 0, st, x0, W.xs[0], B, (int64_t)5,
-                       (int64_t)(T + 1) * 5);
-    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, us_init, W.us[0], B, T, tiled);
-    hipLaunchKernelGGL(k_pack, tile_grid(B, T), dim3(256), 0, st, (const double*)k, W.k[0], B, T, tiled);
-    hipLaunchKernelGGL(k_pack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)K, W.K[0], B, T * 5, tiled);
+    // into the wave-tiled workspace, one launch: x0 goes to rows 0..4 of the (T+1)*5-row state array of each tile
+    {
+        PackJobs Jb;
+        const double* srcs[4] = {x0, us_init, k, K};
+        double* dsts[4] = {W.xs[0], W.us[0], W.k[0], W.K[0]};
+        const int64_t rows[4] = {5, T, T, T * 5}, rows_dst[4] = {(T + 1) * 5, T, T, T * 5};
+        unsigned y = 0;
+        for (int i = 0; i < 4; ++i) {
+            Jb.src[i] = srcs[i];
+            Jb.dst[i] = dsts[i];
+            Jb.R[i] = rows[i];
+            Jb.Rd[i] = rows_dst[i];
+            Jb.y0[i] = y;
+            y += (unsigned)((rows[i] + 63) / 64);
+        }
+        Jb.y0[4] = y;
+        hipLaunchKernelGGL(k_pack_jobs, dim3((unsigned)((B + 63) / 64), y), dim3(256), 0, st, Jb, B);
+    }
     ilqr_trace tr;
     if (trace)
         tr = *trace;
@@ -1336,14 +1467,26 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
     else
         ILQR_LAUNCH_SOLVE(PathQR);
 #undef ILQR_LAUNCH_SOLVE
-    hipLaunchKernelGGL(k_unpack, tile_grid(B, (T + 1) * 5), dim3(256), 0, st, (const double*)W.xs[0],
-                       (const double*)W.xs[1], (const int32_t*)W.sel_traj, xs, B, (T + 1) * 5, tiled);
-    hipLaunchKernelGGL(k_unpack, tile_grid(B, T), dim3(256), 0, st, (const double*)W.us[0],
-                       (const double*)W.us[1], (const int32_t*)W.sel_traj, us, B, T, tiled);
-    hipLaunchKernelGGL(k_unpack, tile_grid(B, T), dim3(256), 0, st, (const double*)W.k[0],
-                       (const double*)W.k[1], (const int32_t*)W.sel_gain, k, B, T, tiled);
-    hipLaunchKernelGGL(k_unpack, tile_grid(B, T * 5), dim3(256), 0, st, (const double*)W.K[0],
-                       (const double*)W.K[1], (const int32_t*)W.sel_gain, K, B, T * 5, tiled);
+    {
+        UnpackJobs Jb;
+        const double* sa[4] = {W.xs[0], W.us[0], W.k[0], W.K[0]};
+        const double* sb[4] = {W.xs[1], W.us[1], W.k[1], W.K[1]};
+        const int32_t* sl[4] = {W.sel_traj, W.sel_traj, W.sel_gain, W.sel_gain};
+        double* dsts[4] = {xs, us, k, K};
+        const int64_t rows[4] = {(T + 1) * 5, T, T, T * 5};
+        unsigned y = 0;
+        for (int i = 0; i < 4; ++i) {
+            Jb.srcA[i] = sa[i];
+            Jb.srcB[i] = sb[i];
+            Jb.sel[i] = sl[i];
+            Jb.dst[i] = dsts[i];
+            Jb.R[i] = rows[i];
+            Jb.y0[i] = y;
+            y += (unsigned)((rows[i] + 63) / 64);
+        }
+        Jb.y0[4] = y;
+        hipLaunchKernelGGL(k_unpack_jobs, dim3((unsigned)((B + 63) / 64), y), dim3(256), 0, st, Jb, B);
+    }
     return hip_status(hipGetLastError());
 }
 
@@ -1579,6 +1722,17 @@ int ilqr_cartpole_plant_step(int64_t B, const double* par, const double* st, con
     PlantP p{par[0], par[1], par[2], par[3], par[4]};
     hipLaunchKernelGGL(k_plant_step, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, as_stream(stream), p,
                        B, st, u, out);
+    return hip_status(hipGetLastError());
+}
+
+int ilqr_cartpole_mpc_advance(int64_t B, int64_t N, const double* par, double* st, const double* us_solved,
+                              double* us_seed, double* u_applied, double* x0_aug, void* stream)
+{
+    if (!par || !st || !us_solved || !us_seed || !u_applied || !x0_aug || B < 1 || N < 1 || us_seed == us_solved)
+        return ILQR_ERR_ARG;
+    PlantP p{par[0], par[1], par[2], par[3], par[4]};
+    hipLaunchKernelGGL(k_mpc_advance, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, as_stream(stream), p, B, N,
+                       st, us_solved, us_seed, u_applied, x0_aug);
     return hip_status(hipGetLastError());
 }
 

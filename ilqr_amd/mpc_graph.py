@@ -1,11 +1,12 @@
 """Closed-loop MPC with the whole control step captured in a HIP graph.
 
 One control step of the receding-horizon loop of the reference's MPC example
-(examples/cartpole_example_mpc.py:66-79 with ilqr_core.py:422-466) is ~30 small launches:
-augment the measured state, pack, solve (<= 10 warm-started iterations), unpack, apply the
-first control to the plant, shift the control sequence.  At a few thousand closed loops the
-launches, not the kernels, set the step time; capturing the step once and replaying the
-graph removes them.  Results are those of ``RecedingHorizonController`` + ``set_state`` bit
+(examples/cartpole_example_mpc.py:66-79 with ilqr_core.py:422-466) is ~30 small launches when
+driven through the generator: augment the measured state, pack, solve (<= 10 warm-started
+iterations), unpack, apply the first control to the plant, shift the control sequence.  At a few
+thousand closed loops the launches, not the kernels, set the step time.  Here the step is four
+launches (pack, solve, unpack, and one kernel for plant + augment + shift), captured once in a
+graph and replayed.  Results are those of ``RecedingHorizonController`` + ``set_state`` bit
 for bit (same kernels, same order).
 """
 import numpy as np
@@ -23,8 +24,8 @@ class GraphedClosedLoop(object):
         self.dyn = controller.dynamics
         self.B, self.N = state.shape[0], controller.N
         dev = state.device
-        self.st = state.clone()
-        self.us = us_init.clone().reshape(self.B, self.N, 1)
+        self.st = state.to(torch.float64).contiguous().clone()
+        self.us = us_init.to(torch.float64).reshape(self.B, self.N, 1).contiguous().clone()
         self.M = controller._model()
         self.kw = dict(tol=tolerance, line_search_steps=line_search_steps, scale=scale, mu_min=controller.mu_min_,
                        mu_max=controller.mu_max_ if controller.mu_max_ else 0.0, delta0=controller.delta_0_)
@@ -41,20 +42,16 @@ class GraphedClosedLoop(object):
                         status=torch.empty(self.B, dtype=torch.int32, device=dev))
         self.ws = torch.empty(_hip.solve_workspace_bytes(self.M, self.B), dtype=torch.uint8, device=dev)
         self.u_applied = torch.empty(self.B, dtype=torch.float64, device=dev)
+        self.x0 = self.dyn.augment_state(self.st).contiguous()  # augmented state the next solve starts from
         self.graph = None
 
     def _one_step(self, O):
-        import torch
-        x0 = self.dyn.augment_state(self.st)
-        _hip.solve(self.M, O, x0.contiguous(), self.us, delta=self.delta, k=self.k, K=self.K, workspace=self.ws,
-                   out=self.out)
-        us_new = self.out["us"]
-        self.u_applied.copy_(us_new[:, 0, 0])
-        st_new = _hip.plant_step(self.st, self.u_applied, gravity=self.env.gravity, masscart=self.env.masscart,
-                                 masspole=self.env.masspole, length=self.env.length, tau=self.env.tau)
-        self.st.copy_(st_new)
-        # next seed: move along the current path and repeat its tail (ilqr_core.py:463-465)
-        self.us.copy_(torch.cat([us_new[:, 1:], us_new[:, -1:]], dim=1))
+        _hip.solve(self.M, O, self.x0, self.us, delta=self.delta, k=self.k, K=self.K, workspace=self.ws, out=self.out)
+        # plant step with the first control, augmented state and control seed of the next solve
+        # (ilqr_core.py:457-465, cartpole_gym.py:60-72, cartpole.py:97-116): one launch
+        _hip.mpc_advance(self.st, self.out["us"], self.us, self.u_applied, self.x0, gravity=self.env.gravity,
+                         masscart=self.env.masscart, masspole=self.env.masspole, length=self.env.length,
+                         tau=self.env.tau)
 
     def first(self, initial_n_iterations=200):
         """The first solve (more iterations), eagerly; then capture the subsequent step."""
@@ -62,7 +59,7 @@ class GraphedClosedLoop(object):
         self._one_step(_hip.Opts(max_iter=initial_n_iterations, **self.kw))
         torch.cuda.synchronize()
         # warm the allocator on a side stream, then capture (the usual torch recipe)
-        keep = [t.clone() for t in (self.st, self.us, self.delta, self.k, self.K, self.u_applied)]
+        keep = [t.clone() for t in (self.st, self.us, self.delta, self.k, self.K, self.u_applied, self.x0)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -73,7 +70,7 @@ class GraphedClosedLoop(object):
         with torch.cuda.graph(self.graph):
             self._one_step(self.O)
         torch.cuda.synchronize()
-        for t, v in zip((self.st, self.us, self.delta, self.k, self.K, self.u_applied), keep):
+        for t, v in zip((self.st, self.us, self.delta, self.k, self.K, self.u_applied, self.x0), keep):
             t.copy_(v)  # capture and warm-up must not advance the loop
         return self.st, self.u_applied
 

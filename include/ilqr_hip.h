@@ -199,6 +199,17 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
 int ilqr_cartpole_plant_step(int64_t B, const double* par, const double* st, const double* u,
                              double* out, void* stream);
 
+/* Everything between two solves of the closed loop of examples/cartpole_example_mpc.py:66-79 (env.step,
+ * set_state) around RecedingHorizonController.control (ilqr/ilqr_core.py:451-465), in one launch:
+ *   u_applied [B]    = us_solved[:, 0]                          the control handed to the plant (:457-459)
+ *   st [B,4]         = _state_eq(st, u_applied)                 in place (cartpole_gym.py:60-72)
+ *   x0_aug [B,5]     = augment_state(st)                        for the next solve (cartpole.py:97-116)
+ *   us_seed [B,N]    = us_solved moved one step along, its last control repeated (:463-465, step_size 1)
+ * us_seed must not alias us_solved.  par as for ilqr_cartpole_plant_step.  Same arithmetic, bit for bit, as
+ * the separate calls. */
+int ilqr_cartpole_mpc_advance(int64_t B, int64_t N, const double* par, double* st, const double* us_solved,
+                              double* us_seed, double* u_applied, double* x0_aug, void* stream);
+
 /* Diagnostic hook (no counterpart in the reference): with a device buffer of
  * 4 * ceil(B/64) uint64 set, every wavefront of the next ilqr_solve_batched launches
  * records [start, end] of its life in 100 MHz ticks, its HW_ID and its XCC id.
