@@ -229,6 +229,37 @@ def test_graphed_closed_loop_equals_the_eager_controller():
     assert eq(graphed["states"], eager["states"]) and eq(graphed["controls"], eager["controls"])
 
 
+def test_mpc_advance_equals_plant_step_augment_and_shift():
+    """The one-launch step between two solves of a closed loop against the oracle's plant step, the
+    oracle's augmentation and a numpy shift, bit for bit; aliasing the seed with the solved sequence is refused."""
+    import ctypes
+    from ilqr_amd import _hip
+    DEV = "cuda:0"
+
+    def dev(a):
+        return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV)
+
+    def oracle_augment(st_):
+        s_, c_, _ = co.detmath(st_[:, 2], st_[:, 2])
+        return np.stack([st_[:, 0], st_[:, 1], s_, c_, st_[:, 3]], axis=1)
+    r = np.random.RandomState(17)
+    B, N = 777, 15
+    st = np.concatenate([r.uniform(-2, 2, (B, 2)), r.uniform(-4, 4, (B, 1)), r.uniform(-3, 3, (B, 1))], axis=1)
+    us = r.uniform(-20, 20, (B, N, 1))
+    d_st, d_us = dev(st), dev(us)
+    d_seed, d_u, d_x0 = torch.empty_like(d_us), torch.empty(B, dtype=torch.float64, device=DEV), \
+        torch.empty((B, 5), dtype=torch.float64, device=DEV)
+    _hip.mpc_advance(d_st, d_us, d_seed, d_u, d_x0)
+    st_ref = co.plant_step(st, us[:, 0, 0])
+    assert eq(d_u.cpu().numpy(), us[:, 0, 0]) and eq(d_st.cpu().numpy(), st_ref)
+    assert eq(d_x0.cpu().numpy(), oracle_augment(st_ref))
+    assert eq(d_seed.cpu().numpy(), np.concatenate([us[:, 1:], us[:, -1:]], axis=1))
+    par = (ctypes.c_double * 5)(9.8, 1.0, 0.1, 0.5, 0.05)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert _hip.lib().ilqr_cartpole_mpc_advance(ctypes.c_int64(B), ctypes.c_int64(N), par, p(d_st), p(d_us), p(d_us), p(d_u),
+                                                p(d_x0), None) == -1
+
+
 def test_pathqrcost_through_the_solver_api(golden_dir):
     """iLQR(dynamics, PathQRCost(...)) as a user of the reference would write it; single problem
     against the recorded reference run, batch against the oracle."""
