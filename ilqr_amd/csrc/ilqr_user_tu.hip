@@ -603,8 +603,8 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
 
 // The general case, 2 <= m <= 4: a direct per-lane evaluation of _backward_pass / _compute_Q_terms /
 // _forward_pass (ilqr_core.py:85-228) with every term of every np.dot as a left-to-right chain, the
-// dense boxQP (boxqp_dense), and the serial first-hit line search.  Written for generality, not
-// speed: the per-problem matrices of the larger sizes live partly in scratch memory.
+// dense boxQP (boxqp_dense), and the cooperative line search of the single-control kernel.  Written for
+// generality first: the per-problem matrices of the larger sizes live partly in scratch memory.
 
 struct GCost { // QRCost (ilqr/ilqr_cost.py:490-530) or PathQRCost (:635-770)
     double Q[UN * UN], Qt[UN * UN], R[UM * UM], xg[UN], ug[UM];
