@@ -4,7 +4,7 @@ profiles/traffic.json (HBM bytes per k_solve launch) from the FETCH_SIZE / WRITE
 
   python scripts/summarise_profiles.py gpurun_out/prof_<tag> <name-prefix>
 
-FETCH_SIZE on gfx950 reports half the bytes actually fetched.  k_pack, whose traffic is known exactly (it
+FETCH_SIZE on gfx950 reports half the bytes actually fetched.  The pack kernel (k_pack_jobs), whose traffic is known exactly (it
 reads every element once and writes it once), calibrates the factor in the same run (k_unpack does not
 qualify: with per-problem source selection it touches cache lines of both copies).  WRITE_SIZE needs no
 correction.
