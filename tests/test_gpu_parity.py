@@ -427,6 +427,22 @@ def test_full_size_batch_properties(hip):
     assert np.array_equal(part["iters"].cpu().numpy(), iters[lo:hi])
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_every_problem_of_a_mid_size_batch_against_the_oracle(hip, seed):
+    """4096 full-length solves (up to 200 iterations, limits active), every problem compared with the
+    oracle: the rare paths (boxQP fallbacks, searches past alpha_0, mu_max exits) occur somewhere in a batch
+    of this size, in wavefronts that are half filled and share workgroups."""
+    B = 4096
+    x0, us0 = co.cartpole_batch(B, seed_x=seed, seed_u=100 + seed)
+    Mo = co.cartpole_model()
+    ref = co.solve(Mo, co.Opts(), x0, us0, nthreads=16, trace=False)
+    out = hip.solve(hip_model(hip, Mo), hip.Opts(), dev(x0), dev(us0))
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "us", "xs", "k", "K", "mu", "delta"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+
+
 def test_one_gpu_share_of_the_million_problem_configuration(hip):
     """131072 problems = one GPU's slice of the 8-GPU, 2^20-problem configuration (4-wave
     workgroups, two rounds of waves per SIMD): the first 16384 are the benchmark batch, so they
