@@ -90,10 +90,11 @@ def test_forward_difference_user_model_equals_oracle(hip):
     compare(out, ref, B)
 
 
-@pytest.mark.parametrize("B,T,max_iter", [(150, 50, 40), (65, 9, 6), (1, 30, 25)])
+@pytest.mark.parametrize("B,T,max_iter", [(150, 50, 40), (65, 9, 6), (1, 30, 25), (1500, 50, 100)])
 def test_two_control_user_model_equals_oracle(hip, B, T, max_iter):
     """m = 2: the general path of the per-model solver (dense boxQP with its index compaction,
-    dense Q-terms, serial line search) against the oracle's generic code on the same source."""
+    dense Q-terms, cooperative line search) against the oracle's generic code on the same source;
+    the largest case runs to the iteration limit and has searches that go past alpha_0."""
     from ilqr_amd import user_model as um
     Mo = rotor(T)
     x0, us0 = rotor_batch(B, T, seed=70 + B)
@@ -106,6 +107,8 @@ def test_two_control_user_model_equals_oracle(hip, B, T, max_iter):
     compare(out, ref, B)
     if B >= 100:
         assert (ref["trace"]["n_clamped"] > 0).any()
+    if B >= 1000:
+        assert (ref["trace"]["alpha_idx"] >= 1).any() and ref["iters"].max() == max_iter
 
 
 def test_two_control_model_through_the_solver_api(hip):
