@@ -102,6 +102,27 @@ def test_large_solve_bit_exact(hip):
     assert (ref["trace"]["n_clamped"] > 0).any() and (ref["status"] == 1).any()
 
 
+def test_large_solve_more_problems_than_wavefronts(hip):
+    """The solve kernel keeps one workgroup per CU resident and hands problems out from a queue: with more
+    problems than the chip has wavefront slots every wavefront solves several, one after the other, and
+    problems with different iteration counts must not disturb each other.  2600 problems (not a multiple
+    of four), short horizon, every output against the oracle."""
+    T, B = 12, 2600
+    Mo, M = models(hip, T)
+    x0, us0 = co.synthetic_batch(B, T=T, seed_x=41, seed_u=42)
+    ref = co.solve(Mo, co.Opts(max_iter=12), x0, us0, nthreads=16, trace=False)
+    out = hip.large_solve(M, hip.Opts(max_iter=12), dev(x0), dev(us0))
+    torch.cuda.synchronize()
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+    assert ref["iters"].min() < ref["iters"].max()
+    # a second call on the same workspace (the queue's counter is reset by the call)
+    again = hip.large_solve(M, hip.Opts(max_iter=12), dev(x0), dev(us0), workspace=out.get("workspace"))
+    assert eq(again["us"].cpu().numpy(), ref["us"])
+
+
 def test_large_model_through_the_solver_api(hip):
     """iLQR(SigmoidLinearDynamics(...), QRCost(...), N).update_u on a batch and, with an
     on_iteration callback, one launch per iteration: both equal the oracle's solve."""
