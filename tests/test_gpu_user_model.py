@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from oracle import c_oracle as co  # noqa: E402
-from test_user_model_cpu import (cartpole_as_user, pendulum, pendulum_batch, pendulum_fd, rotor,  # noqa: E402
-                                 rotor_batch)
+from test_user_model_cpu import (cartpole_as_user, chain, chain_batch, pendulum, pendulum_batch,  # noqa: E402
+                                 pendulum_fd, rotor, rotor_batch)
 
 
 @pytest.fixture(scope="module")
@@ -109,6 +109,23 @@ def test_two_control_user_model_equals_oracle(hip, B, T, max_iter):
         assert (ref["trace"]["n_clamped"] > 0).any()
     if B >= 1000:
         assert (ref["trace"]["alpha_idx"] >= 1).any() and ref["iters"].max() == max_iter
+
+
+@pytest.mark.parametrize("B,T,max_iter", [(130, 30, 30), (700, 20, 40)])
+def test_largest_user_model_equals_oracle(hip, B, T, max_iter):
+    """8 states and 4 controls, the most the per-model solver takes (its matrices spill to scratch memory):
+    every output and the per-iteration trace against the oracle's generic code on the same source."""
+    from ilqr_amd import user_model as um
+    Mo = chain(T)
+    x0, us0 = chain_batch(B, T, seed=300 + B)
+    ref = co.solve(Mo, co.Opts(max_iter=max_iter), x0, us0, nthreads=8)
+    M = um.UserModel(um.load("mass_chain_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower,
+                     Mo.upper)
+    assert (M.n, M.m) == (8, 4)
+    out = um.solve(M, hip.Opts(max_iter=max_iter), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    compare(out, ref, B)
+    assert (ref["trace"]["n_clamped"] > 0).any() and (ref["trace"]["n_clamped"] < 4).any()
 
 
 def test_two_control_model_through_the_solver_api(hip):

@@ -52,6 +52,23 @@ def rotor_batch(B, T, seed=7):
     return x0, r.uniform(-1, 1, (B, T, 2))
 
 
+CHAIN_PARAMS = [0.05, 4.0, 0.5, 0.5]
+
+
+def chain(T):
+    """The largest model the per-model solver takes (tests/models/mass_chain_user.h): 8 states, 4 controls;
+    bring the four masses to rest at their unloaded positions, forces limited to +-0.6."""
+    lib = co.build_user_model(os.path.join(MODELS, "mass_chain_user.h"), "mass_chain_user")
+    Q = np.diag([8.0, 8.0, 8.0, 8.0, 1.0, 1.0, 1.0, 1.0])
+    R = 0.1 * np.eye(4) + 0.02 * np.ones((4, 4))
+    return co.user_model(lib, CHAIN_PARAMS, T, Q, R, 40.0 * np.eye(8), np.zeros(8), None, [-0.6] * 4, [0.6] * 4)
+
+
+def chain_batch(B, T, seed=5):
+    r = np.random.RandomState(seed)
+    return np.concatenate([r.uniform(-0.8, 0.8, (B, 4)), r.uniform(-0.5, 0.5, (B, 4))], axis=1), r.uniform(-1, 1, (B, T, 4))
+
+
 def pendulum_batch(B, T, seed=3):
     r = np.random.RandomState(seed)
     th, w = r.uniform(-np.pi, np.pi, B), r.uniform(-1, 1, B)
@@ -112,6 +129,30 @@ def test_two_control_model_jacobian_and_solve():
     assert (out["J"] < 0.5 * J0).all() and (out["trace"]["n_clamped"] > 0).any()
 
 
+def test_largest_model_jacobian_and_solve():
+    """8 states, 4 controls: the analytic Jacobian against central differences, and the oracle's solve
+    descends with limits active."""
+    T, B = 30, 5
+    M = chain(T)
+    assert (M.n, M.m) == (8, 4)
+    x0, us0 = chain_batch(B, T)
+    f, fx, fu = co.dynamics(M, x0[0], us0[0, 0])
+    eps = 1e-6
+    for j in range(8):
+        d = np.zeros(8)
+        d[j] = eps
+        col = (co.dynamics(M, x0[0] + d, us0[0, 0])[0][0] - co.dynamics(M, x0[0] - d, us0[0, 0])[0][0]) / (2 * eps)
+        np.testing.assert_allclose(fx[0][:, j], col, atol=1e-7)
+    for j in range(4):
+        d = np.zeros(4)
+        d[j] = eps
+        col = (co.dynamics(M, x0[0], us0[0, 0] + d)[0][0] - co.dynamics(M, x0[0], us0[0, 0] - d)[0][0]) / (2 * eps)
+        np.testing.assert_allclose(fu[0][:, j], col, atol=1e-7)
+    J0 = co.rollout_cost(M, x0, us0)[1]
+    out = co.solve(M, co.Opts(max_iter=40), x0, us0)
+    assert (out["J"] < 0.9 * J0).all() and (out["trace"]["n_clamped"] > 0).any()
+
+
 def test_forward_difference_model_follows_approx_fprime():
     """ilqr/ilqr_dynamics.py:145-167: row m of f_x is approx_fprime(x, f(.)[m], x_eps), i.e.
     (f(x + eps e_k) - f(x)) / eps with eps = sqrt(machine epsilon); checked against that formula
@@ -147,11 +188,11 @@ def test_user_model_libraries_export_every_declared_symbol():
     declared = set(re.findall(r"\b(ilqr_user_[a-z0-9_]+)\s*\(", body))
     assert declared == {"ilqr_user_dims", "ilqr_user_controls", "ilqr_user_workspace_bytes", "ilqr_user_solve_batched"}
     for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4)), ("pendulum_fd_user", (3, 4)),
-                       ("planar_rotor_user", (7, 5))):
+                       ("planar_rotor_user", (7, 5)), ("mass_chain_user", (8, 4))):
         um.build_user_model(os.path.join(MODELS, name + ".h"), name)  # hipcc cross-compiles; no-op when up to date
         lib = C.CDLL(um.library_path(name))  # loading needs no GPU
         for sym in declared:
             assert hasattr(lib, sym), (name, sym)
         n, npar = C.c_int32(), C.c_int32()
         assert lib.ilqr_user_dims(C.byref(n), C.byref(npar)) == 0 and (n.value, npar.value) == dims
-        assert lib.ilqr_user_controls() == (2 if name == "planar_rotor_user" else 1)
+        assert lib.ilqr_user_controls() == {"planar_rotor_user": 2, "mass_chain_user": 4}.get(name, 1)
