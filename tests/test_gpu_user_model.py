@@ -12,7 +12,7 @@ torch = pytest.importorskip("torch")
 
 from oracle import c_oracle as co  # noqa: E402
 from test_user_model_cpu import (cartpole_as_user, chain, chain_batch, pendulum, pendulum_batch,  # noqa: E402
-                                 pendulum_fd, rotor, rotor_batch)
+                                 pendulum_fd, rotor, rotor_batch, rotor_fd)
 
 
 @pytest.fixture(scope="module")
@@ -109,6 +109,20 @@ def test_two_control_user_model_equals_oracle(hip, B, T, max_iter):
         assert (ref["trace"]["n_clamped"] > 0).any()
     if B >= 1000:
         assert (ref["trace"]["alpha_idx"] >= 1).any() and ref["iters"].max() == max_iter
+
+
+def test_forward_difference_two_control_model_equals_oracle(hip):
+    """ILQR_USER_FD with a control vector: the device evaluates the same forward differences as the oracle."""
+    from ilqr_amd import user_model as um
+    T, B = 30, 90
+    Mo = rotor_fd(T)
+    x0, us0 = rotor_batch(B, T, seed=121)
+    ref = co.solve(Mo, co.Opts(max_iter=30), x0, us0, nthreads=8)
+    M = um.UserModel(um.load("planar_rotor_fd_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower,
+                     Mo.upper)
+    out = um.solve(M, hip.Opts(max_iter=30), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    compare(out, ref, B)
 
 
 @pytest.mark.parametrize("B,T,max_iter", [(130, 30, 30), (700, 20, 40)])

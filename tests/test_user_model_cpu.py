@@ -44,6 +44,13 @@ def rotor(T):
     return co.user_model(lib, ROTOR_PARAMS, T, Q, R, 50.0 * np.eye(7), xg, None, [-3.0, -3.0], [3.0, 3.0])
 
 
+def rotor_fd(T):
+    """The same vehicle with forward-difference derivatives (two controls)."""
+    lib = co.build_user_model(os.path.join(MODELS, "planar_rotor_fd_user.h"), "planar_rotor_fd_user")
+    Ma = rotor(T)
+    return co.user_model(lib, Ma.user_params, T, Ma.Q, Ma.R, Ma.Qt, Ma.x_goal, None, Ma.lower, Ma.upper)
+
+
 def rotor_batch(B, T, seed=7):
     r = np.random.RandomState(seed)
     phi = r.uniform(-1.0, 1.0, B)
@@ -179,6 +186,23 @@ def test_forward_difference_model_follows_approx_fprime():
     np.testing.assert_allclose(b_["J"], a["J"], rtol=1e-3)
 
 
+def test_forward_difference_model_with_two_controls():
+    """ILQR_USER_FD on a model with a control vector: f_x, f_u within the truncation error of the analytic
+    Jacobian of the same vehicle, and the solve descends."""
+    T, B = 25, 4
+    Ma, Mf = rotor(T), rotor_fd(T)
+    assert (Mf.n, Mf.m) == (7, 2)
+    x0, us0 = rotor_batch(B, T, seed=12)
+    _, fx_a, fu_a = co.dynamics(Ma, x0[1], us0[1, 0])
+    f, fx, fu = co.dynamics(Mf, x0[1], us0[1, 0])
+    np.testing.assert_allclose(fx, fx_a, atol=2e-6)
+    np.testing.assert_allclose(fu, fu_a, atol=2e-6)
+    assert not np.array_equal(fx, fx_a)  # forward differences, not a copy of the analytic entries
+    J0 = co.rollout_cost(Mf, x0, us0)[1]
+    out = co.solve(Mf, co.Opts(max_iter=30), x0, us0)
+    assert (out["J"] < 0.9 * J0).all()
+
+
 def test_user_model_libraries_export_every_declared_symbol():
     import re
     from ilqr_amd import user_model as um
@@ -188,11 +212,12 @@ def test_user_model_libraries_export_every_declared_symbol():
     declared = set(re.findall(r"\b(ilqr_user_[a-z0-9_]+)\s*\(", body))
     assert declared == {"ilqr_user_dims", "ilqr_user_controls", "ilqr_user_workspace_bytes", "ilqr_user_solve_batched"}
     for name, dims in (("cartpole_user", (5, 5)), ("pendulum_user", (3, 4)), ("pendulum_fd_user", (3, 4)),
-                       ("planar_rotor_user", (7, 5)), ("mass_chain_user", (8, 4))):
+                       ("planar_rotor_user", (7, 5)), ("mass_chain_user", (8, 4)),
+                       ("planar_rotor_fd_user", (7, 5))):
         um.build_user_model(os.path.join(MODELS, name + ".h"), name)  # hipcc cross-compiles; no-op when up to date
         lib = C.CDLL(um.library_path(name))  # loading needs no GPU
         for sym in declared:
             assert hasattr(lib, sym), (name, sym)
         n, npar = C.c_int32(), C.c_int32()
         assert lib.ilqr_user_dims(C.byref(n), C.byref(npar)) == 0 and (n.value, npar.value) == dims
-        assert lib.ilqr_user_controls() == {"planar_rotor_user": 2, "mass_chain_user": 4}.get(name, 1)
+        assert lib.ilqr_user_controls() == {"planar_rotor_user": 2, "planar_rotor_fd_user": 2, "mass_chain_user": 4}.get(name, 1)
