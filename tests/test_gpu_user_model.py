@@ -253,3 +253,16 @@ def test_user_model_chunked_solve_with_compaction(hip):
         assert torch.equal(one[key], chunked[key]), key
     it = one["iters"].cpu().numpy()
     assert (it < 50).any() and it.max() > 6
+    # the multi-control kernel continues from carried state the same way
+    T, B = 30, 300
+    Mo = rotor(T)
+    x0, us0 = rotor_batch(B, T, seed=131)
+    M = um.UserModel(um.load("planar_rotor_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower,
+                     Mo.upper)
+    one = um.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0))
+    chunked = compaction.solve_compacting(um.solve, M, {}, 40, dev(x0), dev(us0), chunk=5)
+    torch.cuda.synchronize()
+    for key in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K"):
+        assert torch.equal(one[key], chunked[key]), key
+    it = one["iters"].cpu().numpy()
+    assert (it < 40).any() and it.max() > 5
