@@ -27,6 +27,10 @@ COMPACT_MIN_BATCH = 49152
 COMPACT_CHUNK = 32
 
 
+#: problems in one round of wavefronts on an MI355X: 256 CUs x 4 SIMDs, one 64-problem wavefront each
+ROUND_PROBLEMS = 256 * 4 * 64
+
+
 def solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=None, K=None, chunk=COMPACT_CHUNK,
                      trace=False):
     """``solve_fn``: _hip.solve or user_model.solve (same keywords).  ``opts_kw``: keyword arguments of
@@ -54,7 +58,11 @@ def solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=
     idx = None  # None: every problem is still running and the launches work on the full arrays
     done = 0
     while True:
-        n_it = min(chunk, max_iter - done)
+        n_run = B if idx is None else int(idx.numel())
+        # slightly more problems than one round of wavefronts holds: shorter chunks, so that the running set
+        # is counted again sooner and drops into a single round earlier (the overhang costs most of a round)
+        overhang = ROUND_PROBLEMS < n_run <= ROUND_PROBLEMS + ROUND_PROBLEMS // 6
+        n_it = min(max(1, chunk // 4) if overhang else chunk, max_iter - done)
         if n_it not in opts:
             opts[n_it] = _hip.Opts(max_iter=n_it, mu_from_array=True, **opts_kw)
         if idx is None:

@@ -1601,8 +1601,20 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
     bool full = true;   // all of them: the launches work on the caller's arrays in place
     int done = 0;
     const int max_iter = opts->max_iter;
+    // Problems one round of wavefronts holds (one wavefront of 64 problems per SIMD).  A launch with slightly
+    // more runs a second round for the overhang that costs most of a full one (67185 problems take as long
+    // as 77654), so while the running set is within a sixth above a full round the chunks are a quarter as
+    // long: the set is re-counted sooner and drops into a single round earlier.
+    int64_t round_problems = 256 * 4 * WAVE;
+    {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+            round_problems = (int64_t)n_cu * 4 * WAVE;
+    }
     for (;;) {
-        o.max_iter = std::min<int>(chunk, max_iter - done);
+        const bool overhang = n > round_problems && n <= round_problems + round_problems / 6;
+        o.max_iter = std::min<int>(overhang ? std::max(1, chunk / 4) : chunk, max_iter - done);
         if (full) {
             // (us may alias us_init from the second launch on: the input is packed before the output is written)
             rc = ilqr_solve_batched(model, &o, B, x0, done == 0 ? us_init : us, delta, k, K, xs, us, J, mu, G.iters,
