@@ -59,9 +59,9 @@ def solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=
     done = 0
     while True:
         n_run = B if idx is None else int(idx.numel())
-        # slightly more problems than one round of wavefronts holds: shorter chunks, so that the running set
-        # is counted again sooner and drops into a single round earlier (the overhang costs most of a round)
-        overhang = ROUND_PROBLEMS < n_run <= ROUND_PROBLEMS + ROUND_PROBLEMS // 6
+        # slightly more problems than a whole number of rounds of wavefronts holds: shorter chunks, so that the
+        # running set is counted again sooner and drops a round earlier (the overhang costs most of a round)
+        overhang = n_run > ROUND_PROBLEMS and 0 < n_run % ROUND_PROBLEMS <= ROUND_PROBLEMS // 6
         n_it = min(max(1, chunk // 4) if overhang else chunk, max_iter - done)
         if n_it not in opts:
             opts[n_it] = _hip.Opts(max_iter=n_it, mu_from_array=True, **opts_kw)

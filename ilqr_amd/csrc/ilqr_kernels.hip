@@ -1603,8 +1603,8 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
     const int max_iter = opts->max_iter;
     // Problems one round of wavefronts holds (one wavefront of 64 problems per SIMD).  A launch with slightly
     // more runs a second round for the overhang that costs most of a full one (67185 problems take as long
-    // as 77654), so while the running set is within a sixth above a full round the chunks are a quarter as
-    // long: the set is re-counted sooner and drops into a single round earlier.
+    // as 77654), so while the running set is within a sixth of a round above a whole number of rounds the
+    // chunks are a quarter as long: the set is re-counted sooner and drops a round earlier.
     int64_t round_problems = 256 * 4 * WAVE;
     {
         int dev = 0, n_cu = 0;
@@ -1613,7 +1613,8 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
             round_problems = (int64_t)n_cu * 4 * WAVE;
     }
     for (;;) {
-        const bool overhang = n > round_problems && n <= round_problems + round_problems / 6;
+        const int64_t over = n % round_problems; // problems beyond the last full round
+        const bool overhang = n > round_problems && over > 0 && over <= round_problems / 6;
         o.max_iter = std::min<int>(overhang ? std::max(1, chunk / 4) : chunk, max_iter - done);
         if (full) {
             // (us may alias us_init from the second launch on: the input is packed before the output is written)
