@@ -114,6 +114,7 @@ struct PackJobs {
     int64_t R[4];  // rows of the source, [B, R]
     int64_t Rd[4]; // rows per tile of the wave-tiled destination (>= R: the rows land at the top of the tile)
     unsigned y0[5];
+    const int64_t* idx; // not null: problem b of the launch is row idx[b] of the source arrays
 };
 __global__ __launch_bounds__(256) void k_pack_jobs(PackJobs Jb, int64_t B)
 {
@@ -139,7 +140,12 @@ __global__ __launch_bounds__(256) void k_pack_jobs(PackJobs Jb, int64_t B)
     int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int j = ty; j < 64; j += 4) {
         int64_t b = b0 + j, r = r0 + tx;
-        tile[j][tx] = (b < B && r < R) ? src[b * R + r] : 0.0;
+        double v = 0.0;
+        if (b < B && r < R) {
+            int64_t row = Jb.idx != nullptr ? Jb.idx[b] : b;
+            v = src[row * R + r];
+        }
+        tile[j][tx] = v;
     }
     __syncthreads();
     for (int j = ty; j < 64; j += 4) {
@@ -156,6 +162,7 @@ struct UnpackJobs {
     double* dst[4];
     int64_t R[4];
     unsigned y0[5];
+    const int64_t* idx; // not null: problem b of the launch is row idx[b] of the destination arrays
 };
 __global__ __launch_bounds__(256) void k_unpack_jobs(UnpackJobs Jb, int64_t B)
 {
@@ -193,8 +200,10 @@ __global__ __launch_bounds__(256) void k_unpack_jobs(UnpackJobs Jb, int64_t B)
     __syncthreads();
     for (int j = ty; j < 64; j += 4) {
         int64_t b = b0 + j, r = r0 + tx;
-        if (b < B && r < R)
-            dst[b * R + r] = tile[tx][j];
+        if (b < B && r < R) {
+            int64_t row = Jb.idx != nullptr ? Jb.idx[b] : b;
+            dst[row * R + r] = tile[tx][j];
+        }
     }
 }
 
@@ -1373,10 +1382,15 @@ size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B)
     return (size_t)rows * ld * sizeof(double) + 2 * (size_t)ld * sizeof(int32_t);
 }
 
-int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
-                       const double* us_init, double* delta, double* k, double* K, double* xs,
-                       double* us, double* J, double* mu, int32_t* iters, int32_t* status,
-                       const ilqr_trace* trace, void* workspace, size_t workspace_bytes, void* stream)
+// The solve on problems idx[0..B-1] of the caller's per-problem ARRAYS (x0, us_init, k, K, xs, us: row idx[b]
+// of each belongs to problem b of this launch; idx == nullptr: row b), with the per-problem SCALARS (delta, J,
+// mu, iters, status, trace) compact, [B].  The chunked solve continues its running problems this way without
+// staging copies of their trajectories and gains.
+static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                                 const double* us_init, double* delta, double* k, double* K, double* xs,
+                                 double* us, double* J, double* mu, int32_t* iters, int32_t* status,
+                                 const ilqr_trace* trace, void* workspace, size_t workspace_bytes, void* stream,
+                                 const int64_t* idx)
 {
     int rc = check_model(model);
     if (rc != ILQR_OK)
@@ -1423,6 +1437,7 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
             y += (unsigned)((rows[i] + 63) / 64);
         }
         Jb.y0[4] = y;
+        Jb.idx = idx;
         hipLaunchKernelGGL(k_pack_jobs, dim3((unsigned)((B + 63) / 64), y), dim3(256), 0, st, Jb, B);
     }
     ilqr_trace tr;
@@ -1485,9 +1500,19 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
             y += (unsigned)((rows[i] + 63) / 64);
         }
         Jb.y0[4] = y;
+        Jb.idx = idx;
         hipLaunchKernelGGL(k_unpack_jobs, dim3((unsigned)((B + 63) / 64), y), dim3(256), 0, st, Jb, B);
     }
     return hip_status(hipGetLastError());
+}
+
+int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                       const double* us_init, double* delta, double* k, double* K, double* xs,
+                       double* us, double* J, double* mu, int32_t* iters, int32_t* status,
+                       const ilqr_trace* trace, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return solve_batched_indexed(model, opts, B, x0, us_init, delta, k, K, xs, us, J, mu, iters, status, trace, workspace,
+                                 workspace_bytes, stream, nullptr);
 }
 
 
@@ -1541,7 +1566,7 @@ __global__ __launch_bounds__(256) void k_chunk_init(int64_t B, double* __restric
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 struct ChunkBuffers { // carved out of the caller's workspace behind the solve workspace
-    double *x0, *us, *delta, *k, *K, *mu, *xs, *J;
+    double *delta, *mu, *J; // compact per-problem scalars of the running problems
     int32_t *iters, *status;
     int64_t* idx;
 };
@@ -1555,9 +1580,8 @@ size_t ilqr_solve_chunked_workspace_bytes(const ilqr_model* model, int64_t B)
     size_t base = ilqr_solve_workspace_bytes(model, B);
     if (base == 0)
         return 0;
-    int64_t T = model->T;
-    // gathered copies of every per-problem array + iteration counts, status and the index list
-    size_t doubles = (size_t)B * (5 + T + 1 + T + T * 5 + 1 + (T + 1) * 5 + 1);
+    // compact copies of the per-problem scalars (delta, mu, J) + iteration counts, status and the index list
+    size_t doubles = (size_t)B * 3;
     return base + doubles * sizeof(double) + (size_t)B * (2 * sizeof(int32_t) + sizeof(int64_t)) + 256;
 }
 
@@ -1580,13 +1604,8 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
     ChunkBuffers G;
     {
         double* p = reinterpret_cast<double*>(static_cast<char*>(workspace) + base);
-        G.x0 = p; p += B * 5;
-        G.us = p; p += B * T;
         G.delta = p; p += B;
-        G.k = p; p += B * T;
-        G.K = p; p += B * T * 5;
         G.mu = p; p += B;
-        G.xs = p; p += B * (T + 1) * 5;
         G.J = p; p += B;
         G.idx = reinterpret_cast<int64_t*>(p);
         G.iters = reinterpret_cast<int32_t*>(G.idx + B);
@@ -1631,22 +1650,16 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
             auto scatter = [&](const double* src, double* dst, int64_t row) {
                 hipLaunchKernelGGL(k_scatter_rows, dim3(blocks256(n * row)), dim3(256), 0, st, src, dst, G.idx, n, row);
             };
-            gather(x0, G.x0, 5);
-            gather(us, G.us, T);
+            // trajectories and gains stay where they are (the conversion kernels of the solve follow the index
+            // list); only the per-problem scalars are compacted
             gather(delta, G.delta, 1);
-            gather(k, G.k, T);
-            gather(K, G.K, T * 5);
             gather(mu, G.mu, 1);
-            rc = ilqr_solve_batched(model, &o, n, G.x0, G.us, G.delta, G.k, G.K, G.xs, G.us, G.J, G.mu, G.iters,
-                                    G.status, nullptr, workspace, base, stream);
+            rc = solve_batched_indexed(model, &o, n, x0, us, G.delta, k, K, xs, us, G.J, G.mu, G.iters, G.status, nullptr,
+                                       workspace, base, stream, G.idx);
             if (rc != ILQR_OK)
                 return rc;
-            scatter(G.xs, xs, (T + 1) * 5);
-            scatter(G.us, us, T);
             scatter(G.J, J, 1);
             scatter(G.delta, delta, 1);
-            scatter(G.k, k, T);
-            scatter(G.K, K, T * 5);
             scatter(G.mu, mu, 1);
             hipLaunchKernelGGL(k_chunk_bookkeeping, dim3(blocks256(n)), dim3(256), 0, st, G.iters, G.status,
                                (const int64_t*)G.idx, n, iters, status);

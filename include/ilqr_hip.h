@@ -187,8 +187,9 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
  * delta, k, K), so that finished problems stop costing lanes and memory traffic.  Results are those
  * of ilqr_solve_batched (a continued launch re-rolls the current controls: same inputs, same bits).
  * No counterpart in the reference, which solves one problem at a time.  Arguments as
- * ilqr_solve_batched without the trace; the workspace is larger (gathered copies of the per-problem
- * arrays); us may alias us_init.  Synchronises the stream once per chunk (the next launch is sized
+ * ilqr_solve_batched without the trace; the workspace is slightly larger (the index list of the running
+ * problems and compact copies of their scalars; trajectories and gains are converted in place through
+ * the index list); us may alias us_init.  Synchronises the stream once per chunk (the next launch is sized
  * on the host), so it is not capturable in a HIP graph. */
 size_t ilqr_solve_chunked_workspace_bytes(const ilqr_model* model, int64_t B);
 int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, int32_t chunk, int64_t B,
