@@ -178,3 +178,69 @@ def test_large_model_tracks_a_path_with_pathqrcost(hip):
     xs_ref, J_ref = co.rollout_cost(Mo, x0, us0)
     xs_g, J_g = hip.large_rollout_cost(Mh, dev(x0), dev(us0))
     assert eq(xs_g.cpu().numpy(), xs_ref) and eq(J_g.cpu().numpy(), J_ref)
+
+
+def _compare_solve(out, ref, B, with_trace=True):
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+    if with_trace:
+        tr = {key: out["trace"][key].cpu().numpy().T for key in out["trace"]}
+        for b in range(B):
+            it = int(ref["iters"][b])
+            for key in ("J", "accepted", "alpha_idx", "mu", "delta", "qp_iter", "qp_backtrack", "n_clamped",
+                        "stopped_at"):
+                assert eq(tr[key][b, :it], ref["trace"][key][b, :it]), (b, key)
+
+
+def test_large_solve_at_the_configured_horizon(hip):
+    """The large-state configuration as stated: T = 200, up to 200 iterations, the default options.  The
+    first 16 problems of the benchmark batch, every output and the whole per-iteration trace against the
+    oracle."""
+    T, B = 200, 16
+    Mo, M = models(hip, T)
+    x0, us0 = co.synthetic_batch(B, T=T)
+    ref = co.solve(Mo, co.Opts(), x0, us0, nthreads=16)
+    out = hip.large_solve(M, hip.Opts(), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    _compare_solve(out, ref, B)
+    assert (ref["status"] == 1).all() and ref["iters"].max() > 5
+    assert (ref["trace"]["n_clamped"] > 0).any()  # the box limits bind on this workload
+
+
+def test_large_full_size_batch_properties(hip):
+    """The benchmark batch of the large-state configuration (8192 problems, T = 200, 200 iterations
+    allowed): properties that need no oracle run, a sample of problems against the oracle, and a slice
+    solved alone against the same problems inside the batch."""
+    from ilqr_amd.synthetic import SyntheticWorkload
+    T, B = 200, 8192
+    wl = SyntheticWorkload(T=T)
+    M = wl.device_model()
+    x0, us0 = wl.batch(B)
+    out = hip.large_solve(M, hip.Opts(), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    iters, status, J = out["iters"].cpu().numpy(), out["status"].cpu().numpy(), out["J"].cpu().numpy()
+    assert np.isfinite(J).all() and iters.min() >= 1 and iters.max() <= 200
+    assert set(np.unique(status)) <= {0, 1, 2} and (status == 1).mean() > 0.99
+    trJ, acc = out["trace"]["J"].cpu().numpy(), out["trace"]["accepted"].cpu().numpy()
+    for b in range(0, B, 61):  # the cost never increases; the last entry is the result
+        h = trJ[:iters[b], b]
+        assert (np.diff(h) <= 0).all() and h[-1] == J[b]
+        assert (acc[iters[b]:, b] == -1).all()
+    # the returned states are the rollout of the returned controls, and J is their cost
+    xs2, J2 = hip.large_rollout_cost(M, out["xs"][:, 0].contiguous(), out["us"])
+    assert torch.equal(xs2, out["xs"]) and eq(J2.cpu().numpy(), J)
+    # the slowest problem of the batch and a regular sample, against the oracle
+    idx = np.unique(np.concatenate([np.arange(0, B, 373), [int(iters.argmax())]]))
+    Mo = co.synthetic_model(T=T)
+    ref = co.solve(Mo, co.Opts(), x0[idx], us0[idx], nthreads=16, trace=False)
+    assert np.array_equal(ref["iters"], iters[idx]) and np.array_equal(ref["status"], status[idx])
+    for key in ("J", "us", "xs", "k", "K", "mu", "delta"):
+        assert eq(out[key].cpu().numpy()[idx], ref[key]), key
+    # a slice solved alone gives the same bits as inside the big batch (what sharding relies on)
+    lo, hi = 4096 + 3, 4096 + 3 + 301
+    part = hip.large_solve(M, hip.Opts(), dev(x0[lo:hi]), dev(us0[lo:hi]))
+    for key in ("us", "xs", "J", "K"):
+        assert torch.equal(part[key], out[key][lo:hi]), key
+    assert np.array_equal(part["iters"].cpu().numpy(), iters[lo:hi])

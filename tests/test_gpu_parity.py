@@ -466,6 +466,14 @@ def test_one_gpu_share_of_the_million_problem_configuration(hip):
     xs_bm, J2 = hip.rollout_cost_bm(M, B, hip.pack_bm(out["xs"][:, 0].contiguous()), hip.pack_bm(out["us"]))
     assert eq(J2.cpu().numpy(), J)
     assert eq(hip.unpack_bm(xs_bm, B, (101, 5)).cpu().numpy(), out["xs"].cpu().numpy())
+    del xs_bm, J2, small
+    # the path the solver API and the benchmark take at this size: launches of COMPACT_CHUNK iterations
+    # with the finished problems dropped in between, every output equal to the single launch's
+    from ilqr_amd import compaction
+    chunked = hip.solve_chunked(M, hip.Opts(), dev(x0), dev(us0), compaction.COMPACT_CHUNK)
+    torch.cuda.synchronize()
+    for key in ("xs", "us", "J", "k", "K", "mu", "delta", "iters", "status"):
+        assert torch.equal(out[key], chunked[key]), key
 
 
 def test_boxqp1_on_captured_backward_pass_inputs(hip):
