@@ -49,6 +49,7 @@ class OptsC(C.Structure):
         ("qp_max_iter", C.c_int32), ("pad_", C.c_int32),
         ("qp_min_grad", C.c_double), ("qp_min_rel_improve", C.c_double), ("qp_step_dec", C.c_double),
         ("qp_min_step", C.c_double), ("qp_armijo", C.c_double), ("mu_init", C.c_double),
+        ("dJ_carry", _vp),
     ]
 
 
@@ -159,8 +160,19 @@ class Opts:
         o.qp_min_grad, o.qp_min_rel_improve, o.qp_step_dec = qp_min_grad, qp_min_rel_improve, qp_step_dec
         o.qp_min_step, o.qp_armijo = qp_min_step, qp_armijo
         o.mu_init = 0.0 if mu_from_array else -1.0
+        o.dJ_carry = None
         self.c = o
         self.max_iter = int(max_iter)
+
+    def carrying(self, dJ):
+        """The C struct with ``dJ_carry`` pointing at ``dJ`` ([2, B] fp64 device tensor or None) for one call:
+        the expected-improvement sums Delta_J1 / Delta_J2 of a solve that is cut into several calls."""
+        import torch
+        if dJ is not None:
+            assert dJ.dim() == 2 and dJ.shape[0] == 2
+            _req(dJ, torch.float64)
+        self.c.dJ_carry = None if dJ is None else dJ.data_ptr()
+        return self.c
 
 
 def _ptr(t):
@@ -274,11 +286,12 @@ TRACE_FIELDS = (("J", "f8"), ("accepted", "i4"), ("alpha_idx", "i4"), ("mu", "f8
                 ("qp_iter", "i4"), ("qp_backtrack", "i4"), ("n_clamped", "i4"), ("stopped_at", "i4"))
 
 
-def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, out=None, mu=None):
+def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, out=None, mu=None, dJ=None):
     """ilqr_solve_batched on ref-layout tensors.  Returns a dict of device tensors.
 
     ``out`` may carry preallocated result tensors (keys xs, us, J, mu, iters,
     status) and ``workspace`` a uint8 tensor, so that a timed loop allocates nothing.
+    ``dJ`` [2, B]: Delta_J1 / Delta_J2 carried between the calls of a solve cut into several (in/out).
     """
     import torch
     B = x0.shape[0]
@@ -303,7 +316,7 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
     if mu is not None:
         res["mu"] = mu
     need = solve_workspace_bytes(M, B)
-    if workspace is None:
+    if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     tr_c, tr = None, None
     if trace:
@@ -316,7 +329,7 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
             tr[name] = t
             setattr(tr_c, name, t.data_ptr())
     check(lib().ilqr_solve_batched(
-        C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(x0), _ptr(us_init), _ptr(_req(delta, torch.float64)),
+        C.byref(M.c), C.byref(O.carrying(dJ)), C.c_int64(B), _ptr(x0), _ptr(us_init), _ptr(_req(delta, torch.float64)),
         _ptr(_req(k, torch.float64)), _ptr(_req(K, torch.float64)), _ptr(res["xs"]), _ptr(res["us"]),
         _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),
         C.byref(tr_c) if tr_c is not None else None, _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
@@ -345,7 +358,7 @@ def solve_chunked(M, O, x0, us_init, chunk, delta=None, k=None, K=None, workspac
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     check(L.ilqr_solve_batched_chunked(
-        C.byref(M.c), C.byref(O.c), C.c_int32(int(chunk)), C.c_int64(B), _ptr(x0), _ptr(us_init),
+        C.byref(M.c), C.byref(O.carrying(None)), C.c_int32(int(chunk)), C.c_int64(B), _ptr(x0), _ptr(us_init),
         _ptr(_req(delta, f64)), _ptr(_req(k, f64)), _ptr(_req(K, f64)), _ptr(res["xs"]), _ptr(res["us"]), _ptr(res["J"]),
         _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]), _ptr(workspace), C.c_size_t(workspace.numel()),
         _stream()))
@@ -481,7 +494,7 @@ def large_forward_ls(M, alphas, xs, us, k, K, store_idx=-1):
     return J, xs_new, us_new
 
 
-def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, mu=None):
+def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, mu=None, dJ=None):
     import torch
     B, dev = x0.shape[0], x0.device
     T, n, m = M.T, M.n, M.m
@@ -495,7 +508,7 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
                iters=torch.empty(B, dtype=torch.int32, device=dev),
                status=torch.empty(B, dtype=torch.int32, device=dev))
     need = int(lib().ilqr_large_workspace_bytes(C.byref(M.c), C.c_int64(B)))
-    if workspace is None:
+    if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     tr_c, tr = None, None
     if trace:
@@ -508,7 +521,7 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
             tr[name] = t
             setattr(tr_c, name, t.data_ptr())
     check(lib().ilqr_large_solve_batched(
-        C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(x0, torch.float64)), _ptr(_req(us_init, torch.float64)),
+        C.byref(M.c), C.byref(O.carrying(dJ)), C.c_int64(B), _ptr(_req(x0, torch.float64)), _ptr(_req(us_init, torch.float64)),
         _ptr(_req(delta, torch.float64)), _ptr(_req(k, torch.float64)), _ptr(_req(K, torch.float64)),
         _ptr(res["xs"]), _ptr(res["us"]), _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),
         C.byref(tr_c) if tr_c is not None else None, _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))

@@ -9,11 +9,12 @@ iterations") are gathered into a dense sub-batch and continued from their carrie
 mu, delta and the gains k, K.  A continued launch re-rolls the current controls (same inputs, same
 bits, same cost) and proceeds exactly as the single launch would have: the iterates, iteration
 counts and results are identical (the per-iteration callback mode of ``iLQR.update_u`` relies on the
-same property with chunks of one iteration).  For the built-in cart-pole path the same loop exists
-behind the C ABI (``ilqr_solve_batched_chunked``); this module serves the per-model libraries and
-callers that want the per-iteration trace.  The one state that does not survive a launch boundary
-is the pair of expected-improvement sums of the previous backward pass, which the single launch
-re-uses only after a backward pass that has given up on a non-finite Q_uu at mu_max.
+same property with chunks of one iteration).  The expected-improvement sums Delta_J1 / Delta_J2 of
+the last backward pass travel with the problem too (``dJ_carry`` of the C options): the reference
+re-uses them when a backward pass gives up on a non-finite Q_uu at mu_max (ilqr_core.py:291-305).
+For the built-in cart-pole path the same loop exists behind the C ABI
+(``ilqr_solve_batched_chunked``); this module serves the per-model libraries and callers that want
+the per-iteration trace.
 
 Worth it only when the batch fills the GPU (tens of thousands of problems); below that a launch is
 as long as its slowest problem whatever the others do.
@@ -43,6 +44,7 @@ def solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=
     k = torch.zeros((B, T, m), dtype=f64, device=dev) if k is None else k
     K = torch.zeros((B, T, m, n), dtype=f64, device=dev) if K is None else K
     mu = torch.ones(B, dtype=f64, device=dev)
+    dJ = torch.zeros((2, B), dtype=f64, device=dev)  # Delta_J1, Delta_J2 of each problem's last backward pass
     iters = torch.zeros(B, dtype=torch.int32, device=dev)
     status = torch.full((B,), _hip.STATUS_RAN_OUT, dtype=torch.int32, device=dev)
     x0 = x0.reshape(B, n)
@@ -66,15 +68,16 @@ def solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=
         if n_it not in opts:
             opts[n_it] = _hip.Opts(max_iter=n_it, mu_from_array=True, **opts_kw)
         if idx is None:
-            res = solve_fn(M, opts[n_it], x0, us, delta=delta, k=k, K=K, mu=mu, trace=trace, workspace=ws)
+            res = solve_fn(M, opts[n_it], x0, us, delta=delta, k=k, K=K, mu=mu, trace=trace, workspace=ws, dJ=dJ)
             ws = res["workspace"]
             xs, us, J = res["xs"], res["us"], res["J"]
             iters += res["iters"]
             status = res["status"]
         else:
-            d_i, k_i, K_i, mu_i = delta[idx], k[idx], K[idx], mu[idx]
-            res = solve_fn(M, opts[n_it], x0[idx], us[idx], delta=d_i, k=k_i, K=K_i, mu=mu_i, trace=trace, workspace=ws)
-            delta[idx], k[idx], K[idx], mu[idx] = d_i, k_i, K_i, mu_i
+            d_i, k_i, K_i, mu_i, dJ_i = delta[idx], k[idx], K[idx], mu[idx], dJ[:, idx].contiguous()
+            res = solve_fn(M, opts[n_it], x0[idx], us[idx], delta=d_i, k=k_i, K=K_i, mu=mu_i, trace=trace, workspace=ws,
+                           dJ=dJ_i)
+            delta[idx], k[idx], K[idx], mu[idx], dJ[:, idx] = d_i, k_i, K_i, mu_i, dJ_i
             xs[idx], us[idx], J[idx] = res["xs"], res["us"], res["J"]
             iters[idx] += res["iters"]
             status[idx] = res["status"]

@@ -104,6 +104,7 @@ struct SolveOptsP {
     double tol, scale, mu_min, mu_max, delta0;
     double alphas[32];
     QPOptsP qp;
+    double* dJ_carry; // [2, B] or null: Delta_J1 / Delta_J2 carried from one launch to the next (ilqr_core.py:278-279, :305)
 };
 
 // ---- cart-pole dynamics -----------------------------------------------------

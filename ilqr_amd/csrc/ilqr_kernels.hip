@@ -743,6 +743,10 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     }
 
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
+    if (valid && O.mu_from_array && O.dJ_carry != nullptr) { // a continued solve: the sums of its last backward pass
+        dJ1 = O.dJ_carry[gb];
+        dJ2 = O.dJ_carry[B + gb];
+    }
     int converged = 0, status = ILQR_RAN_OUT;
     int iters = 0;
     bool running = valid && O.max_iter > 0;
@@ -891,6 +895,10 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         status_out[gb] = status;
         W.sel_traj[gb] = cur;
         W.sel_gain[gb] = gcur;
+        if (O.dJ_carry != nullptr) {
+            O.dJ_carry[gb] = dJ1;
+            O.dJ_carry[B + gb] = dJ2;
+        }
     }
     if (wave_log != nullptr && lane == 0 && valid)
         wave_log[wave_global * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1178,6 +1186,7 @@ int fill_opts(const ilqr_opts* o, SolveOptsP& s)
     s.mu_min = o->mu_min;
     s.mu_max = o->mu_max;
     s.delta0 = o->delta0;
+    s.dJ_carry = o->dJ_carry;
     for (int i = 0; i < 32; ++i)
         s.alphas[i] = i < o->n_alpha ? o->alphas[i] : 0.0;
     return fill_qp(o, s.qp);
@@ -1567,6 +1576,7 @@ inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 struct ChunkBuffers { // carved out of the caller's workspace behind the solve workspace
     double *delta, *mu, *J; // compact per-problem scalars of the running problems
+    double *dJ, *dJ_all;    // Delta_J1 / Delta_J2 of the last backward pass: [2, n] of the running problems, [2, B] of all
     int32_t *iters, *status;
     int64_t* idx;
 };
@@ -1580,8 +1590,9 @@ size_t ilqr_solve_chunked_workspace_bytes(const ilqr_model* model, int64_t B)
     size_t base = ilqr_solve_workspace_bytes(model, B);
     if (base == 0)
         return 0;
-    // compact copies of the per-problem scalars (delta, mu, J) + iteration counts, status and the index list
-    size_t doubles = (size_t)B * 3;
+    // compact copies of the per-problem scalars (delta, mu, J, Delta_J1, Delta_J2), Delta_J1 / Delta_J2 of every
+    // problem, iteration counts, status and the index list
+    size_t doubles = (size_t)B * 7;
     return base + doubles * sizeof(double) + (size_t)B * (2 * sizeof(int32_t) + sizeof(int64_t)) + 256;
 }
 
@@ -1607,12 +1618,17 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
         G.delta = p; p += B;
         G.mu = p; p += B;
         G.J = p; p += B;
+        G.dJ = p; p += 2 * B;
+        G.dJ_all = p; p += 2 * B;
         G.idx = reinterpret_cast<int64_t*>(p);
         G.iters = reinterpret_cast<int32_t*>(G.idx + B);
         G.status = G.iters + B;
     }
     ilqr_opts o = *opts;
-    o.mu_init = 0.0; // every launch starts from the mu array
+    o.mu_init = 0.0; // every launch starts from the mu array ...
+    // ... and from the Delta_J sums of the problem's last backward pass (zeros at the start: ilqr_core.py:278-279)
+    if (hipMemsetAsync(G.dJ_all, 0, (size_t)2 * B * sizeof(double), st) != hipSuccess)
+        return ILQR_ERR_HIP;
     hipLaunchKernelGGL(k_chunk_init, dim3(blocks256(B)), dim3(256), 0, st, B, mu, iters, status);
     std::vector<int32_t> h_status((size_t)B);
     std::vector<int64_t> h_idx;
@@ -1637,6 +1653,7 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
         o.max_iter = std::min<int>(overhang ? std::max(1, chunk / 4) : chunk, max_iter - done);
         if (full) {
             // (us may alias us_init from the second launch on: the input is packed before the output is written)
+            o.dJ_carry = G.dJ_all;
             rc = ilqr_solve_batched(model, &o, B, x0, done == 0 ? us_init : us, delta, k, K, xs, us, J, mu, G.iters,
                                     G.status, nullptr, workspace, base, stream);
             if (rc != ILQR_OK)
@@ -1654,6 +1671,9 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
             // list); only the per-problem scalars are compacted
             gather(delta, G.delta, 1);
             gather(mu, G.mu, 1);
+            gather(G.dJ_all, G.dJ, 1);
+            gather(G.dJ_all + B, G.dJ + n, 1);
+            o.dJ_carry = G.dJ; // [2, n]
             rc = solve_batched_indexed(model, &o, n, x0, us, G.delta, k, K, xs, us, G.J, G.mu, G.iters, G.status, nullptr,
                                        workspace, base, stream, G.idx);
             if (rc != ILQR_OK)
@@ -1661,6 +1681,8 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
             scatter(G.J, J, 1);
             scatter(G.delta, delta, 1);
             scatter(G.mu, mu, 1);
+            scatter(G.dJ, G.dJ_all, 1);
+            scatter(G.dJ + n, G.dJ_all + B, 1);
             hipLaunchKernelGGL(k_chunk_bookkeeping, dim3(blocks256(n)), dim3(256), 0, st, G.iters, G.status,
                                (const int64_t*)G.idx, n, iters, status);
         }

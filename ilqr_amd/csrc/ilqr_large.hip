@@ -144,6 +144,7 @@ struct LSolveOpts {
     double tol, scale, mu_min, mu_max, delta0;
     double alphas[32];
     LQPOpts qp;
+    double* dJ_carry; // [2, B] or null: Delta_J1 / Delta_J2 carried from one launch to the next
 };
 
 constexpr int LQ_TAB = 512; // Armijo steps tabulated per workgroup
@@ -1153,6 +1154,10 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P, const LSolveOpt
     double delta = delta_io[b];
     int status = ILQR_RAN_OUT, iters = 0;
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0; // carried over iterations, as in the reference
+    if (O.mu_from_array && O.dJ_carry != nullptr) { // a continued solve: the sums of its last backward pass
+        dJ1 = O.dJ_carry[b];
+        dJ2 = O.dJ_carry[B + b];
+    }
     wave_sync();
 
     for (int it = 0; it < O.max_iter; ++it) {
@@ -1270,6 +1275,10 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P, const LSolveOpt
         mu_out[b] = mu;
         iters_out[b] = iters;
         status_out[b] = status;
+        if (O.dJ_carry != nullptr) {
+            O.dJ_carry[b] = dJ1;
+            O.dJ_carry[B + b] = dJ2;
+        }
     }
     wave_sync(); // the wave's LDS region is reused by its next problem
 }
@@ -1477,6 +1486,7 @@ int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opt
     O.mu_min = opts->mu_min;
     O.mu_max = opts->mu_max;
     O.delta0 = opts->delta0;
+    O.dJ_carry = opts->dJ_carry;
     for (int i = 0; i < 32; ++i)
         O.alphas[i] = i < opts->n_alpha ? opts->alphas[i] : 0.0;
     rc = large_qp(opts, O.qp);

@@ -438,6 +438,10 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
         J = uforward(P, C, T, ld, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
     }
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
+    if (valid && O.mu_from_array && O.dJ_carry != nullptr) { // a continued solve: the sums of its last backward pass
+        dJ1 = O.dJ_carry[b];
+        dJ2 = O.dJ_carry[B + b];
+    }
     int status = ILQR_RAN_OUT, iters = 0;
     bool running = valid && O.max_iter > 0;
     const int n_more = O.n_alpha - 1; // candidates after alpha_0
@@ -592,6 +596,10 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
         mu_out[b] = mu;
         iters_out[b] = iters;
         status_out[b] = status;
+        if (O.dJ_carry != nullptr) {
+            O.dJ_carry[b] = dJ1;
+            O.dJ_carry[B + b] = dJ2;
+        }
     }
 #undef XS
 #undef US
@@ -995,6 +1003,10 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
         J = gforward(P, C, T, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
     }
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
+    if (valid && O.mu_from_array && O.dJ_carry != nullptr) { // a continued solve: the sums of its last backward pass
+        dJ1 = O.dJ_carry[b];
+        dJ2 = O.dJ_carry[B + b];
+    }
     int status = ILQR_RAN_OUT, iters = 0;
     bool running = valid && O.max_iter > 0;
     const int n_more = O.n_alpha - 1; // candidates after alpha_0
@@ -1149,6 +1161,10 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
         mu_out[b] = mu;
         iters_out[b] = iters;
         status_out[b] = status;
+        if (O.dJ_carry != nullptr) {
+            O.dJ_carry[b] = dJ1;
+            O.dJ_carry[B + b] = dJ2;
+        }
     }
 #undef XS
 #undef US
@@ -1294,6 +1310,7 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
     O.mu_min = opts->mu_min;
     O.mu_max = opts->mu_max;
     O.delta0 = opts->delta0;
+    O.dJ_carry = opts->dJ_carry;
     for (int i = 0; i < 32; ++i)
         O.alphas[i] = i < opts->n_alpha ? opts->alphas[i] : 0.0;
     O.qp.max_iter = opts->qp_max_iter;

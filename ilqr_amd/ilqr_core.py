@@ -242,6 +242,7 @@ class iLQR(BaseTrajOptimizer):
         B = x0_d.shape[0]
         dev = x0_d.device
         mu = torch.ones(B, dtype=torch.float64, device=dev)
+        dJ = torch.zeros((2, B), dtype=torch.float64, device=dev)  # Delta_J1, Delta_J2: loop-carried (:278-279, :305)
         iters = torch.zeros(B, dtype=torch.int32, device=dev)
         status = torch.zeros(B, dtype=torch.int32, device=dev)
         xs = torch.empty((B, self.N + 1, x0_d.shape[1]), dtype=torch.float64, device=dev)
@@ -261,7 +262,7 @@ class iLQR(BaseTrajOptimizer):
             everyone = bool(active_h.all())
             if everyone:
                 # nothing has finished yet: the solver works on the full arrays in place
-                res = self._solve(M, O, x0_d, us, delta=delta, k=k, K=K, mu=mu, trace=True, workspace=ws)
+                res = self._solve(M, O, x0_d, us, delta=delta, k=k, K=K, mu=mu, trace=True, workspace=ws, dJ=dJ)
                 ws = res["workspace"]
                 xs, us, J = res["xs"], res["us"], res["J"]
                 iters += 1
@@ -270,9 +271,10 @@ class iLQR(BaseTrajOptimizer):
             else:
                 idx = torch.tensor(np.nonzero(active_h)[0], device=dev)
                 d_i, k_i, K_i, mu_i = delta[idx].contiguous(), k[idx].contiguous(), K[idx].contiguous(), mu[idx].contiguous()
+                dJ_i = dJ[:, idx].contiguous()
                 res = self._solve(M, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
-                                  trace=True)
-                delta[idx], k[idx], K[idx], mu[idx] = d_i, k_i, K_i, mu_i
+                                  trace=True, dJ=dJ_i)
+                delta[idx], k[idx], K[idx], mu[idx], dJ[:, idx] = d_i, k_i, K_i, mu_i, dJ_i
                 xs[idx], us[idx], J[idx] = res["xs"], res["us"], res["J"]
                 iters[idx] += 1
                 status[idx] = res["status"]

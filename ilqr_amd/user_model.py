@@ -97,7 +97,7 @@ def load(name):
     return lib
 
 
-def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, mu=None):
+def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, mu=None, dJ=None):
     """ilqr_user_solve_batched on reference-layout device tensors (same dict as _hip.solve)."""
     import torch
     B, dev = x0.shape[0], x0.device
@@ -110,8 +110,8 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
                J=torch.empty(B, dtype=f64, device=dev), mu=torch.ones(B, dtype=f64, device=dev) if mu is None else mu,
                iters=torch.empty(B, dtype=torch.int32, device=dev), status=torch.empty(B, dtype=torch.int32, device=dev))
     need = int(M.lib.ilqr_user_workspace_bytes(C.byref(M.c), C.c_int64(B)))
-    if workspace is None:
-        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    if workspace is None or workspace.numel() < need:  # (the need is not monotone in B: fewer problems per
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)  # wavefront below 32768 problems)
     tr_c, tr = None, None
     if trace:
         tr, tr_c = {}, _hip.TraceC()
@@ -122,7 +122,7 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
             setattr(tr_c, name, t.data_ptr())
     p, req = _hip._ptr, _hip._req
     _hip.check(M.lib.ilqr_user_solve_batched(
-        C.byref(M.c), C.byref(O.c), C.c_int64(B), p(req(x0.reshape(B, n), f64)), p(req(us_init.reshape(B, T, m), f64)),
+        C.byref(M.c), C.byref(O.carrying(dJ)), C.c_int64(B), p(req(x0.reshape(B, n), f64)), p(req(us_init.reshape(B, T, m), f64)),
         p(req(delta, f64)), p(req(k, f64)), p(req(K, f64)), p(res["xs"]), p(res["us"]), p(res["J"]), p(res["mu"]),
         p(res["iters"]), p(res["status"]), C.byref(tr_c) if tr_c is not None else None, p(workspace),
         C.c_size_t(workspace.numel()), _hip._stream()))

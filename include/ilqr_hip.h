@@ -79,6 +79,12 @@ typedef struct ilqr_opts {
      * read from the `mu` output array instead (in/out), which lets a caller run
      * the loop one iteration per call (on_iteration callbacks, :342-345). */
     double mu_init;
+    /* DEVICE [2, B] or NULL.  Delta_J1 and Delta_J2 of update_u (ilqr_core.py:278-279, :289) are loop-carried:
+     * after a backward pass that gives up at mu_max (:291-299) the line search runs on the sums of the previous
+     * iteration (:305).  A caller that cuts one solve into several calls (mu_init >= 0) hands this array to each
+     * of them: it is read on entry when mu_init >= 0 (a fresh solve starts from zeros, :278-279) and written on
+     * exit, Delta_J1 of problem b at [b], Delta_J2 at [B + b]. */
+    double* dJ_carry;
 } ilqr_opts;
 
 /* Optional per-iteration record of ilqr_solve_batched, each array [max_iter, B]
@@ -184,8 +190,9 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
 /* The same solve for batches that fill the GPU, cut into launches of `chunk` iterations: after each
  * launch the problems whose update_u loop has ended (converged, mu >= mu_max: ilqr_core.py:325-339)
  * are dropped and the rest continues as a dense sub-batch from its carried state (controls, mu,
- * delta, k, K), so that finished problems stop costing lanes and memory traffic.  Results are those
- * of ilqr_solve_batched (a continued launch re-rolls the current controls: same inputs, same bits).
+ * delta, k, K and the Delta_J sums of its last backward pass), so that finished problems stop costing
+ * lanes and memory traffic.  Results are those of ilqr_solve_batched (a continued launch re-rolls the
+ * current controls: same inputs, same bits).  opts->dJ_carry is ignored (the sums live in the workspace).
  * No counterpart in the reference, which solves one problem at a time.  Arguments as
  * ilqr_solve_batched without the trace; the workspace is slightly larger (the index list of the running
  * problems and compact copies of their scalars; trajectories and gains are converted in place through

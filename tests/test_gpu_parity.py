@@ -622,3 +622,41 @@ def test_every_launch_shape_gives_the_same_bits(hip):
                 os.environ.pop(key, None)
             else:
                 os.environ[key] = val
+
+
+def test_backward_pass_giving_up_at_mu_max_reuses_the_previous_sums_across_launches(hip):
+    """ilqr_core.py:287-313: when the backward pass raises LinAlgError (non-finite Q_uu) and the retry loop
+    gives up at mu_max, the line search still runs, on the gains and on the Delta_J1 / Delta_J2 of the
+    PREVIOUS iteration.  Forced here with a coarse time step (f_u > 1), a line search that never accepts
+    (scale = 1e30) and delta_ = 1e102: mu climbs 1 -> 2e102 -> 8e204 -> 6.4e307, where Q_uu overflows.
+    The single launch, launches of one iteration (where the sums have to travel between launches) and the
+    C-level chunked solve must all agree with the oracle, including the index at which that last line
+    search ended (30 = every alpha tried; 0 would mean the sums were lost)."""
+    from ilqr_amd import compaction
+    B, T = 70, 6
+    Mo = co.cartpole_model(T=T, dt=1.5)
+    M = hip_model(hip, Mo)
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=5, seed_u=6)
+    x0[:, [0, 1, 4]] *= 0.1
+    us0 *= 0.1
+    kw = dict(scale=1e30, mu_max=1.5e308)
+    d0 = np.full(B, 1e102)
+    ref = co.solve(Mo, co.Opts(max_iter=8, **kw), x0, us0, delta=d0, nthreads=8)
+    gave_up = (ref["iters"] == 4) & (ref["trace"]["alpha_idx"][:, 3] == 30)
+    assert gave_up.sum() > B // 2  # the path really occurs
+    one = hip.solve(M, hip.Opts(max_iter=8, **kw), dev(x0), dev(us0), delta=dev(d0), trace=True)
+    step = compaction.solve_compacting(hip.solve, M, kw, 8, dev(x0), dev(us0), delta=dev(d0), chunk=1, trace=True)
+    for out in (one, step):
+        assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        for key in ("J", "xs", "us", "k", "K", "mu", "delta"):
+            assert eq(out[key].cpu().numpy(), ref[key]), key
+        for key in ("alpha_idx", "accepted", "J", "mu", "delta", "stopped_at"):
+            tr = out["trace"][key].cpu().numpy().T
+            for b in range(B):
+                it = int(ref["iters"][b])
+                assert eq(tr[b, :it], ref["trace"][key][b, :it]), (key, b)
+    for chunk in (1, 3):
+        ch = hip.solve_chunked(M, hip.Opts(max_iter=8, **kw), dev(x0), dev(us0), chunk, delta=dev(d0))
+        for key in ("xs", "us", "J", "k", "K", "mu", "delta", "iters", "status"):
+            assert torch.equal(one[key], ch[key]), (chunk, key)
