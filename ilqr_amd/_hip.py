@@ -67,7 +67,7 @@ EXPORTS = (
     "ilqr_version", "ilqr_status_string", "ilqr_bm_ld", "ilqr_pack_bm", "ilqr_unpack_bm",
     "ilqr_rollout_cost_bm", "ilqr_deriv_bm", "ilqr_backward_bm", "ilqr_forward_ls_bm",
     "ilqr_boxqp_batched", "ilqr_solve_workspace_bytes", "ilqr_solve_batched",
-    "ilqr_solve_chunked_workspace_bytes", "ilqr_solve_batched_chunked",
+    "ilqr_solve_chunked_workspace_bytes", "ilqr_solve_batched_chunked", "ilqr_solve_batched_static",
     "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
     "ilqr_large_rollout_cost", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
     "ilqr_large_solve_batched", "ilqr_large_debug_profile", "ilqr_cartpole_mpc_advance",
@@ -335,6 +335,30 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
         C.byref(tr_c) if tr_c is not None else None, _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
     res.update(delta=delta, k=k, K=K, trace=tr, workspace=workspace)
     return res
+
+
+STATIC_WORKSPACE_BYTES = 32 << 20
+
+
+def solve_static(M, O, x0, us_init, delta, k, K, out, trace=None):
+    """ilqr_solve_batched_static: the solve on the library's own fixed workspace; the call allocates nothing.
+    Every tensor is the caller's: delta [B], k [B,T,m], K [B,T,m,n] (in/out) and ``out`` with xs, us, J, mu,
+    iters, status.  ``trace``: None or a dict of [max_iter, B] tensors keyed as TRACE_FIELDS."""
+    import torch
+    B = x0.shape[0]
+    f64, i32 = torch.float64, torch.int32
+    tr_c = None
+    if trace is not None:
+        tr_c = TraceC()
+        for name, _ in TRACE_FIELDS:
+            setattr(tr_c, name, trace[name].data_ptr())
+    check(lib().ilqr_solve_batched_static(
+        C.byref(M.c), C.byref(O.carrying(None)), C.c_int64(B), _ptr(_req(x0, f64)), _ptr(_req(us_init, f64)),
+        _ptr(_req(delta, f64)), _ptr(_req(k, f64)), _ptr(_req(K, f64)), _ptr(_req(out["xs"], f64)),
+        _ptr(_req(out["us"], f64)), _ptr(_req(out["J"], f64)), _ptr(_req(out["mu"], f64)),
+        _ptr(_req(out["iters"], i32)), _ptr(_req(out["status"], i32)), C.byref(tr_c) if tr_c is not None else None,
+        _stream()))
+    return out
 
 
 def solve_chunked(M, O, x0, us_init, chunk, delta=None, k=None, K=None, workspace=None):

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <mutex>
 
 #include "../../include/ilqr_hip.h"
 #include "ilqr_device.hpp"
@@ -1522,6 +1523,64 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
 {
     return solve_batched_indexed(model, opts, B, x0, us_init, delta, k, K, xs, us, J, mu, iters, status, trace, workspace,
                                  workspace_bytes, stream, nullptr);
+}
+
+} // extern "C" (interrupted for the library-owned workspace of ilqr_solve_batched_static)
+
+// The workspace of ilqr_solve_batched_static: device memory that belongs to the library, one copy per GPU the
+// library is loaded on, held until the process ends.  In host code the array's NAME is only a handle for
+// hipGetSymbolAddress; the address the kernels are given is looked up once per device and kept in
+// g_static_ws[device].
+static __device__ __align__(256) unsigned char g_static_scratch[ILQR_STATIC_WORKSPACE_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_static_ws[MAX_DEVICES]; // device address of g_static_scratch on each device, null until looked up
+std::mutex g_static_ws_mutex;
+
+// Address of the current device's copy of g_static_scratch (looked up on the first call on that device).
+int static_workspace(void** out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
+        return ILQR_ERR_HIP;
+    std::lock_guard<std::mutex> lock(g_static_ws_mutex);
+    if (g_static_ws[dev] == nullptr) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)) != hipSuccess || p == nullptr)
+            return ILQR_ERR_HIP;
+        g_static_ws[dev] = p;
+    }
+    *out = g_static_ws[dev];
+    return ILQR_OK;
+}
+} // namespace
+
+extern "C" {
+
+int ilqr_solve_batched_static(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                              const double* us_init, double* delta, double* k, double* K, double* xs, double* us,
+                              double* J, double* mu, int32_t* iters, int32_t* status, const ilqr_trace* trace,
+                              void* stream)
+{
+    int rc = check_model(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (B < 1)
+        return ILQR_ERR_ARG;
+    // every array of the launch lives in the fixed workspace: larger problems are refused, not truncated
+    if (ilqr_solve_workspace_bytes(model, B) > (size_t)ILQR_STATIC_WORKSPACE_BYTES)
+        return ILQR_ERR_WORKSPACE;
+    void* ws = nullptr;
+    rc = static_workspace(&ws);
+    if (rc != ILQR_OK)
+        return rc;
+    // Nothing in the workspace has to start at zero: the conversion kernel writes x0, the controls and the
+    // gains of the B problems of this call before the solve kernel reads them, the second copies and the
+    // selectors are written before they are read, and columns beyond B are never read, so what an earlier
+    // (larger) call has left behind is dead data.
+    return solve_batched_indexed(model, opts, B, x0, us_init, delta, k, K, xs, us, J, mu, iters, status, trace, ws,
+                                 (size_t)ILQR_STATIC_WORKSPACE_BYTES, stream, nullptr);
 }
 
 

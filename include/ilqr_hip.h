@@ -187,6 +187,22 @@ int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B
                        const ilqr_trace* trace, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ilqr_solve_batched for callers that cannot allocate device memory and have no workspace to pass: code
+ * under HIP graph capture, tight control loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference.  Arguments and results as ilqr_solve_batched without the workspace: the ping-pong copies of
+ * the trajectories and gains live in a buffer of ILQR_STATIC_WORKSPACE_BYTES that belongs to the library
+ * (one per GPU, held until the process ends), and the call allocates and frees nothing.  Returns
+ * ILQR_ERR_WORKSPACE when ilqr_solve_workspace_bytes(model, B) exceeds that size (32 MiB: e.g. 11 000 problems
+ * at T = 15, 1 700 at T = 100).  All calls on one GPU share the buffer: calls that may overlap on one GPU
+ * (different streams, different threads) race -- serialise them, or use ilqr_solve_batched with workspaces of
+ * their own.  The first call on a device looks the buffer's address up (hipGetSymbolAddress); make it
+ * outside a graph capture. */
+#define ILQR_STATIC_WORKSPACE_BYTES (32u << 20)
+int ilqr_solve_batched_static(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                              const double* us_init, double* delta, double* k, double* K, double* xs,
+                              double* us, double* J, double* mu, int32_t* iters, int32_t* status,
+                              const ilqr_trace* trace, void* stream);
+
 /* The same solve for batches that fill the GPU, cut into launches of `chunk` iterations: after each
  * launch the problems whose update_u loop has ended (converged, mu >= mu_max: ilqr_core.py:325-339)
  * are dropped and the rest continues as a dense sub-batch from its carried state (controls, mu,
