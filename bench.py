@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the batched control-limited iLQR solve (cart-pole swing-up, T=100, fp64).
 
-One "step" = one call of ilqr_solve_batched over a batch of 16384 random
-swing-up problems per GPU, inputs already resident in HBM: the whole update_u
-loop (<= 200 iterations, every problem to its own termination) in one launch.
-With N GPUs every rank solves its own 16384 problems (weak scaling: problems
-are independent, no collective inside the solve) and the step ends with the
-RCCL gather of costs, iteration counts and trajectories on rank 0.
+One "step" = one solve of this rank's batch of random swing-up problems, inputs already
+resident in HBM: the whole update_u loop (<= 200 iterations, every problem to its own
+termination) on the device, one launch up to 32768 problems per GPU and launches of 32
+iterations with the finished problems dropped in between above that.
+
+  python bench.py                        16384 problems on one GPU (the benchmark configuration)
+  ... --gpus N                           weak scaling: every rank solves its own 16384 problems
+  ... --gpus N --total 1048576           strong scaling: the million-problem configuration, the batch cut
+                                         into contiguous slices with ilqr_amd.sharding.shard_bounds
+Problems are independent, so there is no collective inside the solve; with N > 1 every step ends with
+the gather of costs, iteration counts and trajectories on rank 0 (RCCL over xGMI), overlapped with the
+next step's solve.
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,18 +29,30 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU = 16384
 T = 100
-# Algorithmic HBM bytes of one iLQR iteration of one cart-pole problem when derivative
-# tensors are streamed through HBM between a derivative kernel, the backward pass and
-# the line search: 8 B x (2 x (T*D + n + n^2) + 2 x ((T+1)n + Tm) + 2 x T(m + mn)),
-# D = 2n^2 + 2nm + n + m + m^2, n = 5, m = 1, T = 100.
+N_STATE, N_CTRL = 5, 1
+# HBM bytes of one iLQR iteration of one cart-pole problem.
+#  * staged design (derivative tensors streamed through HBM between a derivative kernel, the backward pass and
+#    the line search): 8 B x (2 x (T*D + n + n^2) + 2 x ((T+1)n + Tm) + 2 x T(m + mn)), D = 2n^2 + 2nm + n + m + m^2
+#  * fused design (what k_solve does: derivatives evaluated in registers): the backward sweep reads xs, us and
+#    writes k, K; the accepted rollout reads xs, us, k, K and writes xs, us
 D_STEP = 2 * 25 + 2 * 5 + 5 + 1 + 1
-BYTES_PER_PROBLEM_ITER = 8 * (2 * (T * D_STEP + 5 + 25) + 2 * ((T + 1) * 5 + T) + 2 * T * 6)
+STAGED_BYTES_PER_PROBLEM_ITER = 8 * (2 * (T * D_STEP + 5 + 25) + 2 * ((T + 1) * 5 + T) + 2 * T * 6)
+FUSED_READ_BYTES = 8 * (((T + 1) * 5 + T) + ((T + 1) * 5 + T + T * 6))
+FUSED_WRITE_BYTES = 8 * (T * 6 + ((T + 1) * 5 + T))
 # fp64 operations of one iteration: backward sweep (T x (4n^3 + 10mn^2 + 6m^2 n + ...)) ~ 90 kflop,
 # one line-search rollout ~ T x 150 flop (+ 3 transcendental calls per step).
 FLOP_BACKWARD = 90e3
 FLOP_ROLLOUT = T * 150.0
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6
+N_SIMD = 1024  # 256 CUs x 4
+# The reference as written (its own iLQR.update_u, Python, dynamics through a sympy-lambdified stand-in for the
+# Theano model) on the single-problem example, timed once in the build container (one Xeon core): it cannot
+# travel to the GPU box, so the number is a recorded constant, not a measurement of this run.
+REFERENCE_AS_WRITTEN = {"value": 0.07, "unit": "solves/s", "cores": 1,
+                        "sample": "examples/cartpole_example.py configuration, 200 iterations in 13.9 s "
+                                  "(69 ms per iteration), CPython 3.10, one Xeon core of the build container; "
+                                  "recorded, not measured by this run"}
 
 
 def make_batch(B, seed):
@@ -63,8 +81,94 @@ def cpu_baseline(n_problems, threads):
     dt = time.perf_counter() - t0
     return dict(value=n_problems / dt, unit="solves/s", cores=threads, kind="port",
                 sample="first %d of the %d problems of rank 0, C port of the reference algorithm "
-                       "(oracle/ilqr_oracle.c, gcc -O2, OpenMP over problems), %.1f s wall, "
-                       "mean %.1f iterations/solve" % (n_problems, B_PER_GPU, dt, float(out["iters"].mean())))
+                       "(oracle/ilqr_oracle.c: gcc -O2 -ffp-contract=off, OpenMP over problems, its own "
+                       "deterministic sin/cos/atan2 instead of libm so that results equal the GPU's bit for "
+                       "bit), %.1f s wall, mean %.1f iterations/solve"
+                       % (n_problems, B_PER_GPU, dt, float(out["iters"].mean())),
+                reference_as_written=REFERENCE_AS_WRITTEN)
+
+
+class ShardedSolveJob(object):
+    """The benchmark step of one rank: solve the rank's problems into one of ``n_sets`` sets of result
+    tensors, then hand that set to the gather pipeline (N > 1), which moves it to rank 0 while the next
+    step's solve runs into the other set.
+
+    solve_into(out): runs the solve, writing xs, us, J, iters, status (and whatever else it likes) into
+        the tensors of the dict ``out`` -- the same tensors every time the set comes round again.
+    out_sets: the result sets (dicts of preallocated tensors, leading dimension = problems of this rank).
+    pipe: ilqr_amd.sharding.GatherPipeline or None (single rank).
+    before_submit: called between the solve and the gather (the gloo rehearsal synchronises the device
+        there; RCCL orders the gather behind the solve on the stream by itself).
+    """
+    GATHERED = ("J", "iters", "status", "xs", "us")
+
+    def __init__(self, solve_into, out_sets, pipe=None, before_submit=None):
+        self.solve_into, self.out_sets, self.pipe, self.before_submit = solve_into, out_sets, pipe, before_submit
+        self.n_steps = 0
+
+    def step(self):
+        slot = self.n_steps % len(self.out_sets)
+        self.n_steps += 1
+        out = self.out_sets[slot]
+        if self.pipe is not None:
+            self.pipe.reclaim(slot)  # the set's previous gather is ordered before the solve that overwrites it
+        self.solve_into(out)
+        if self.pipe is not None:  # the only exchange of the path: results to rank 0
+            if self.before_submit is not None:
+                self.before_submit()
+            self.pipe.submit(slot, {name: out[name] for name in self.GATHERED})
+        return slot
+
+    def finish(self):
+        if self.pipe is not None:
+            self.pipe.drain()  # orders the stream behind every gather issued so far
+
+    def last_slot(self):
+        return (self.n_steps - 1) % len(self.out_sets)
+
+
+def run_steps(job, steps, warmup, barrier, record=None):
+    """W untimed steps, then exactly K timed ones between two barriers.  Returns the wall time of the K
+    steps on this rank.  ``record(i, "start" | "end")`` brackets every timed step (device events)."""
+    for _ in range(warmup):
+        job.step()
+    job.finish()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if record is not None:
+            record(i, "start")
+        job.step()
+        if record is not None:
+            record(i, "end")
+    job.finish()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def sector_granular_factor(iters, group=8):
+    """HBM moves 64-byte sectors = 8 consecutive problems of one row of the batch-minor workspace, and a
+    sector is read or written while ANY of its 8 problems is still iterating.  Returns
+    (sum over groups of 8 of their longest solve x 8) / (sum of the problems' iterations): the factor by
+    which memory traffic exceeds the per-problem byte count."""
+    it = np.asarray(iters, dtype=np.int64)
+    pad = (-len(it)) % group
+    if pad:
+        it = np.concatenate([it, np.zeros(pad, dtype=np.int64)])
+    return float(it.reshape(-1, group).max(1).sum() * group) / max(float(it.sum()), 1.0)
+
+
+def load_counters(workload, batch):
+    """The PMC-derived numbers of this workload and batch size (profiles/solve_counters.json, written by
+    scripts/summarise_profiles.py from the rocprofv3 passes named inside it), or None."""
+    path = os.path.join(ROOT, "profiles", "solve_counters.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        for entry in json.load(fh).get("entries", []):
+            if entry.get("workload") == workload and entry.get("batch") == batch:
+                return entry
+    return None
 
 
 def main_large(args):
@@ -130,6 +234,7 @@ def main_large(args):
         flop_fw = TL * (3 * 2 * n * n + 2 * 2 * n * m + 2 * m * m)
         flops = float(iters.sum()) * (flop_bw + flop_fw)
         tf = flops / (step_ms * 1e-3) / 1e12
+        cnt = load_counters("large", B)
         line = {
             "metric": "iLQR solves/sec (batched synthetic n=32 m=8 T=200, fp64)",
             "value": world * B * args.steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -142,12 +247,15 @@ def main_large(args):
                        "mean_iterations_per_solve": float(iters.mean()), "max_iterations": int(iters.max()),
                        "converged_fraction": float((status == 1).mean())},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                         "traffic": cnt.get("hbm_bytes_per_launch") if cnt else None,
                          "kernel": "k_large_solve (whole update_u loop, one problem per wavefront)",
                          "kernel_ms": step_ms,
                          "note": "algorithmic flops = problem-iterations x (T x 225 kflop backward + T x 7.3 kflop "
                                  "for the accepted rollout); fp64 MFMA peak = fp64 vector peak on MI355X"},
         }
+        if cnt:
+            line["roofline"]["counters"] = cnt
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(16, os.cpu_count() or 1))
             n_cpu = 128
@@ -158,10 +266,76 @@ def main_large(args):
             dt = time.perf_counter() - t1
             line["cpu_baseline"] = dict(value=n_cpu / dt, unit="solves/s", cores=threads, kind="port",
                                         sample="first %d problems of rank 0, C port of the reference algorithm "
-                                               "(OpenMP over problems), %.1f s wall" % (n_cpu, dt))
+                                               "(gcc -O2 -ffp-contract=off, OpenMP over problems), %.1f s wall"
+                                               % (n_cpu, dt))
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cartpole_roofline(B, iters, kernel_ms, chunked):
+    """The roofline object of the cart-pole solve.  Live: the kernel time (device events) and everything
+    derived from the iteration counts of this run.  From profiles/solve_counters.json (rocprofv3 PMC passes
+    over this same command): measured HBM traffic and the VALU-busy fractions."""
+    prob_iters = int(iters.sum())
+    dur_s = kernel_ms * 1e-3
+    cnt = load_counters("cartpole", B)
+    sector = sector_granular_factor(iters)
+    fused_bytes = prob_iters * (FUSED_READ_BYTES + FUSED_WRITE_BYTES)
+    flops = prob_iters * (FLOP_BACKWARD + FLOP_ROLLOUT)
+    staged = {"algorithmic_bytes_per_launch": prob_iters * STAGED_BYTES_PER_PROBLEM_ITER,
+              "GBps_equivalent": prob_iters * STAGED_BYTES_PER_PROBLEM_ITER / dur_s / 1e9,
+              "frac_of_hbm_peak": prob_iters * STAGED_BYTES_PER_PROBLEM_ITER / dur_s / 1e9 / HBM_PEAK_GBS,
+              "note": "problem-iterations x %d B: what a derivative-kernel / backward / line-search pipeline that "
+                      "streams the derivative tensors through HBM would move; the kernel does not move these "
+                      "bytes (derivatives are evaluated in registers), so this is a comparison with that "
+                      "design, not a utilisation" % STAGED_BYTES_PER_PROBLEM_ITER}
+    fused = {"bytes_per_problem_iteration": FUSED_READ_BYTES + FUSED_WRITE_BYTES,
+             "bytes_per_launch": fused_bytes,
+             "sector_granularity_factor": sector,
+             "expected_hbm_bytes_per_launch": fused_bytes * sector,
+             "note": "xs, us in / k, K out (backward sweep) + xs, us, k, K in / xs, us out (accepted rollout); "
+                     "memory moves 64-byte sectors = 8 neighbouring problems, alive until the slowest of the 8 "
+                     "has ended, hence the factor"}
+    traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
+    kernel = ("k_solve (whole update_u loop, one launch per step; its pack/unpack transposes are inside the "
+              "timed span)" if not chunked else
+              "k_solve in launches of 32 iterations, finished problems dropped in between (index-list "
+              "conversions inside the timed span)")
+    hbm_bound = B >= 65536  # one 64-problem wavefront on every SIMD: the ping-pong workspace streams through HBM
+    if hbm_bound:
+        moved = traffic if traffic else fused_bytes * (1.0 if chunked else sector)
+        roof = {"bound": "hbm", "achieved": moved / dur_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": moved / dur_s / 1e9 / HBM_PEAK_GBS,
+                "basis": "PMC-measured bytes" if traffic else "fused-design bytes of this run's iteration counts"}
+    else:
+        # up to 32768 problems every wavefront has a SIMD to itself and the time is the latency of one
+        # wavefront's instruction stream: the resource in use is VALU issue
+        roof = {"bound": "fp64_valu_issue", "unit": "fraction of the chip's SIMD cycles with a VALU instruction "
+                                                    "in flight", "peak": 1.0}
+        if cnt and cnt.get("valu_busy_frac_of_chip") is not None:
+            roof.update(achieved=cnt["valu_busy_frac_of_chip"], frac=cnt["valu_busy_frac_of_chip"],
+                        valu_busy_frac_per_wave=cnt.get("valu_busy_frac_per_wave"),
+                        simd_occupancy=cnt.get("simd_occupancy"),
+                        lane_weighted_frac=cnt.get("valu_lane_weighted_frac_of_chip"),
+                        basis="SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves / %d SIMDs (%s)"
+                              % (N_SIMD, ", ".join(cnt.get("source", []))))
+        else:  # no profile of this batch size: the flop model is all there is
+            roof.update(achieved=flops / dur_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                        frac=flops / dur_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                        basis="no PMC profile for this batch size: fp64 flop model / vector peak")
+    roof.update(traffic=traffic, kernel=kernel, kernel_ms=kernel_ms,
+                hbm={"measured_bytes_per_launch": traffic,
+                     "measured_GBps": traffic / dur_s / 1e9 if traffic else None,
+                     "measured_frac_of_peak": traffic / dur_s / 1e9 / HBM_PEAK_GBS if traffic else None,
+                     "peak_GBps": HBM_PEAK_GBS},
+                fused_design=fused, staged_design=staged,
+                fp64_flops={"achieved_tflops": flops / dur_s / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                            "frac": flops / dur_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                            "flop_model": "problem-iterations x (90 kflop backward + 15 kflop per rollout)"})
+    if cnt:
+        roof["counters"] = cnt
+    return roof
 
 
 def main():
@@ -173,6 +347,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=None,
                     help="problems per GPU (default: %d cart-pole problems, 8192 large-state problems)" % B_PER_GPU)
+    ap.add_argument("--total", type=int, default=None,
+                    help="strong scaling: this many problems in all, cut into contiguous slices over the ranks "
+                         "(1048576 = the million-problem configuration)")
     ap.add_argument("--cpu-sample", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -184,7 +361,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ilqr_amd import _hip
+    from ilqr_amd import _hip, compaction, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -206,100 +383,96 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    B = args.batch if args.batch is not None else B_PER_GPU
     Q, R, Qt, xg = cartpole_cost()
     M = _hip.Model(T, Q, R, Qt, xg, None, [-5.0], [5.0], dt=0.05)
     O = _hip.Opts()
-    x0_h, us_h = make_batch(B, rank)
+    if args.total is not None:  # strong scaling: one global batch (generated per 16384-problem block, so that a
+        # rank only materialises its own slice), cut into contiguous slices
+        sizes = sharding.shard_sizes(args.total, world)
+        lo, hi = sharding.shard_bounds(args.total, world, rank)
+        blocks = range(lo // B_PER_GPU, (hi - 1) // B_PER_GPU + 1)
+        parts = [make_batch(B_PER_GPU, blk) for blk in blocks]
+        off = lo - blocks[0] * B_PER_GPU
+        x0_h = np.concatenate([p[0] for p in parts])[off:off + hi - lo]
+        us_h = np.concatenate([p[1] for p in parts])[off:off + hi - lo]
+        B = hi - lo
+    else:
+        B = args.batch if args.batch is not None else B_PER_GPU
+        sizes = [B] * world
+        x0_h, us_h = make_batch(B, rank)
     x0 = torch.tensor(x0_h, device=dev)
     us0 = torch.tensor(us_h, device=dev)
-    ws = torch.empty(_hip.solve_workspace_bytes(M, B), dtype=torch.uint8, device=dev)
+    chunked = B >= compaction.COMPACT_MIN_BATCH  # the product's policy for batches that fill the GPU
+    ws = [None]
     # Result tensors: with more than one rank two sets alternate, so that the gather of one solve's
-    # results (on the collective's stream) overlaps the next solve.
+    # results (on the collective's stream) overlaps the next solve.  Sets hold max(sizes) rows (slices of
+    # unequal size are gathered padded).
     n_sets = 2 if world > 1 else 1
-    out_sets = [dict(xs=torch.empty((B, T + 1, 5), dtype=torch.float64, device=dev),
-                     us=torch.empty((B, T, 1), dtype=torch.float64, device=dev),
-                     J=torch.empty(B, dtype=torch.float64, device=dev),
-                     mu=torch.empty(B, dtype=torch.float64, device=dev),
-                     iters=torch.empty(B, dtype=torch.int32, device=dev),
-                     status=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
-    delta = torch.empty(B, dtype=torch.float64, device=dev)
-    k = torch.empty((B, T, 1), dtype=torch.float64, device=dev)
-    K = torch.empty((B, T, 1, 5), dtype=torch.float64, device=dev)
-    from ilqr_amd import compaction, sharding
-    cws = [None]  # workspace of the chunked solve, kept across steps
-    pipe = sharding.GatherPipeline(depth=n_sets, dst=0) if world > 1 else None
-    n_steps = [0]
+    rows = max(sizes)
+    f64, i32 = torch.float64, torch.int32
+    out_sets = [dict(xs=torch.zeros((rows, T + 1, 5), dtype=f64, device=dev),
+                     us=torch.zeros((rows, T, 1), dtype=f64, device=dev),
+                     J=torch.zeros(rows, dtype=f64, device=dev), mu=torch.zeros(rows, dtype=f64, device=dev),
+                     iters=torch.zeros(rows, dtype=i32, device=dev),
+                     status=torch.zeros(rows, dtype=i32, device=dev)) for _ in range(n_sets)]
+    delta = torch.empty(B, dtype=f64, device=dev)
+    k = torch.empty((B, T, 1), dtype=f64, device=dev)
+    K = torch.empty((B, T, 1, 5), dtype=f64, device=dev)
 
-    def step():
-        slot = n_steps[0] % n_sets
-        n_steps[0] += 1
-        out_buf = out_sets[slot]
-        if pipe is not None:
-            pipe.reclaim(slot)  # the set's previous gather is ordered before the solve that overwrites it
+    def solve_into(out):
         # a freshly constructed solver per step: delta_ = 2, k_ = K_ = 0 (ilqr_core.py:58-65)
         delta.fill_(2.0)
         k.zero_()
         K.zero_()
-        if B >= compaction.COMPACT_MIN_BATCH:  # the product's policy for batches that fill the GPU
-            res = _hip.solve_chunked(M, O, x0, us0, compaction.COMPACT_CHUNK, delta=delta, k=k, K=K, workspace=cws[0])
-            cws[0] = res["workspace"]
-            for name in out_buf:
-                out_buf[name] = res[name]
+        mine = {name: t[:B] for name, t in out.items()}  # (a view of the leading rows is contiguous)
+        if chunked:
+            res = _hip.solve_chunked(M, O, x0, us0, compaction.COMPACT_CHUNK, delta=delta, k=k, K=K,
+                                     workspace=ws[0], out=mine)
         else:
-            res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws, out=out_buf)
-        if pipe is not None:  # the only exchange of the path: results to rank 0 over xGMI
-            if backend != "nccl":  # rehearsal only: gloo's gathers of GPU tensors hang behind a running kernel
-                torch.cuda.synchronize()
-            pipe.submit(slot, {name: out_buf[name] for name in ("J", "iters", "status", "xs", "us")})
-        return res
+            res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws[0], out=mine)
+        ws[0] = res["workspace"]
+
+    pipe = sharding.GatherPipeline(depth=n_sets, dst=0) if world > 1 else None
+    # rehearsal only: gloo's gathers of GPU tensors hang behind a running kernel
+    job = ShardedSolveJob(solve_into, out_sets, pipe,
+                          before_submit=torch.cuda.synchronize if backend != "nccl" else None)
 
     def barrier():
-        if pipe is not None:
-            pipe.drain()  # orders the stream behind every gather issued so far
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        step()
-        ev[i][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = run_steps(job, args.steps, args.warmup, barrier,
+                        record=lambda i, what: ev[i][0 if what == "start" else 1].record())
     step_ms_events = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=f64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    out_buf = out_sets[(n_steps[0] - 1) % n_sets]
-    iters = out_buf["iters"].cpu().numpy().astype(np.int64)
-    status = out_buf["status"].cpu().numpy()
-    J = out_buf["J"].cpu().numpy()
+    out_buf = out_sets[job.last_slot()]
+    iters = out_buf["iters"][:B].cpu().numpy().astype(np.int64)
+    status = out_buf["status"][:B].cpu().numpy()
+    J = out_buf["J"][:B].cpu().numpy()
     if rank == 0:
+        total = int(sum(sizes))
         ms_per_step = elapsed / args.steps * 1e3
-        solves_per_s = world * B * args.steps / elapsed
-        prob_iters = int(iters.sum())
+        solves_per_s = total * args.steps / elapsed
         max_iters = int(iters.max())
-        alg_bytes = prob_iters * BYTES_PER_PROBLEM_ITER
-        dur_s = step_ms_events * 1e-3
-        achieved = alg_bytes / dur_s / 1e9
-        flops = prob_iters * (FLOP_BACKWARD + FLOP_ROLLOUT)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("batch") == B and tj.get("kernel") == "k_solve":
-                traffic = tj.get("hbm_bytes_per_launch")
+        gathered_ok = None
+        if pipe is not None:  # the last step's results as rank 0 received them: its own slice must be intact
+            g = pipe.result(job.last_slot(), "J")
+            gathered_ok = bool(torch.equal(g.reshape(world, rows)[0, :B], out_buf["J"][:B]))
+        if args.total is not None:
+            workload = ("%d cart-pole swing-up problems in all, cut into %d contiguous slices (%s per GPU), T=100, "
+                        "n=5, m=1, control limits +-5 active, <=200 iterations, tol 1e-4, 30-alpha schedule"
+                        % (total, world, "/".join(str(s) for s in sorted(set(sizes)))))
+        else:
+            workload = ("batched cartpole swing-up, %d random initial states per GPU, T=100, n=5, m=1, "
+                        "control limits +-5 active, <=200 iterations, tol 1e-4, 30-alpha schedule" % B)
         line = {
             "metric": "iLQR solves/sec (batched cartpole T=100, fp64)",
             "value": solves_per_s,
@@ -310,31 +483,20 @@ def main():
             "ms_per_step": ms_per_step,
             "ms_per_iteration": ms_per_step / max(max_iters, 1),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total is not None else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "batched cartpole swing-up, %d random initial states per GPU, T=100, n=5, m=1, "
-                                   "control limits +-5 active, <=200 iterations, tol 1e-4, 30-alpha schedule" % B,
-                       "problems_per_gpu": B, "horizon": T, "parallelism": "batch-sharded x%d" % world,
+            "config": {"workload": workload, "problems_per_gpu": B, "problems_total": total, "horizon": T,
+                       "parallelism": "batch-sharded x%d, results gathered on rank 0" % world,
+                       "solve": "chunked (launches of %d iterations)" % compaction.COMPACT_CHUNK if chunked
+                                else "single launch",
                        "mean_iterations_per_solve": float(iters.mean()), "max_iterations": max_iters,
                        "converged_fraction": float((status == 1).mean()), "mean_final_cost": float(J.mean())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("k_solve (whole update_u loop, one launch per step; its pack/unpack "
-                                    "transposes are inside the timed span)" if B < compaction.COMPACT_MIN_BATCH else
-                                    "k_solve in launches of %d iterations, finished problems dropped in between "
-                                    "(gathers and transposes inside the timed span)" % compaction.COMPACT_CHUNK),
-                         "kernel_ms": step_ms_events,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = problem-iterations x %d B (derivative tensors streamed "
-                                 "through HBM); the kernel fuses derivative evaluation into the sweeps, so its "
-                                 "real HBM traffic is far lower and the binding resource is FP64 VALU issue"
-                                 % BYTES_PER_PROBLEM_ITER},
-            "fp64_valu": {"achieved_tflops": flops / dur_s / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                          "frac": flops / dur_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                          "flop_model": "problem-iterations x (90 kflop backward + 15 kflop per rollout)"},
+            "roofline": cartpole_roofline(B, iters, step_ms_events, chunked),
         }
+        if gathered_ok is not None:
+            line["config"]["gather_check"] = gathered_ok
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(16, os.cpu_count() or 1))
             line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, B), threads)

@@ -361,9 +361,10 @@ def solve_static(M, O, x0, us_init, delta, k, K, out, trace=None):
     return out
 
 
-def solve_chunked(M, O, x0, us_init, chunk, delta=None, k=None, K=None, workspace=None):
+def solve_chunked(M, O, x0, us_init, chunk, delta=None, k=None, K=None, workspace=None, out=None):
     """ilqr_solve_batched_chunked: launches of ``chunk`` iterations, finished problems dropped in
-    between.  Same dict as ``solve`` (no trace)."""
+    between.  Same dict as ``solve`` (no trace); ``out`` may carry preallocated result tensors
+    (xs, us, J, mu, iters, status)."""
     import torch
     B, dev = x0.shape[0], x0.device
     T, n, m = M.T, M.n, M.m
@@ -373,9 +374,16 @@ def solve_chunked(M, O, x0, us_init, chunk, delta=None, k=None, K=None, workspac
     delta = torch.full((B,), 2.0, dtype=f64, device=dev) if delta is None else delta
     k = torch.zeros((B, T, m), dtype=f64, device=dev) if k is None else k
     K = torch.zeros((B, T, m, n), dtype=f64, device=dev) if K is None else K
-    res = dict(xs=torch.empty((B, T + 1, n), dtype=f64, device=dev), us=torch.empty((B, T, m), dtype=f64, device=dev),
-               J=torch.empty(B, dtype=f64, device=dev), mu=torch.empty(B, dtype=f64, device=dev),
-               iters=torch.empty(B, dtype=torch.int32, device=dev), status=torch.empty(B, dtype=torch.int32, device=dev))
+    if out is not None:
+        res = {name: out[name] for name in ("xs", "us", "J", "mu", "iters", "status")}
+        for name, t in res.items():
+            _req(t, torch.int32 if name in ("iters", "status") else f64)
+            assert t.shape[0] == B, name
+    else:
+        res = dict(xs=torch.empty((B, T + 1, n), dtype=f64, device=dev), us=torch.empty((B, T, m), dtype=f64, device=dev),
+                   J=torch.empty(B, dtype=f64, device=dev), mu=torch.empty(B, dtype=f64, device=dev),
+                   iters=torch.empty(B, dtype=torch.int32, device=dev),
+                   status=torch.empty(B, dtype=torch.int32, device=dev))
     L = lib()
     L.ilqr_solve_chunked_workspace_bytes.restype = C.c_size_t
     need = int(L.ilqr_solve_chunked_workspace_bytes(C.byref(M.c), C.c_int64(B)))

@@ -107,3 +107,68 @@ def test_two_rank_gloo_pipelined_gathers_deliver_every_set(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _bench_job_worker(rank, world, port, total, T, out_dir):
+    """bench.py's own step wiring (ShardedSolveJob + run_steps + GatherPipeline) on two gloo ranks, with the
+    device solve replaced by the oracle on CPU tensors: slices of unequal size, result sets that alternate."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    from oracle import c_oracle as co
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x0, us0 = co.cartpole_batch(total, T=T, seed_x=81, seed_u=82)
+        Mo = co.cartpole_model(T=T)
+        sizes = sharding.shard_sizes(total, world)
+        lo, hi = sharding.shard_bounds(total, world, rank)
+        B, rows = hi - lo, max(sizes)
+        out_sets = [dict(xs=torch.zeros((rows, T + 1, 5), dtype=torch.float64), us=torch.zeros((rows, T, 1), dtype=torch.float64),
+                         J=torch.zeros(rows, dtype=torch.float64), iters=torch.zeros(rows, dtype=torch.int32),
+                         status=torch.zeros(rows, dtype=torch.int32)) for _ in range(2)]
+        calls = []
+
+        def solve_into(out):
+            # every step solves a different problem family (more iterations allowed), so that a set that was
+            # not rewritten, or a gather of the wrong set, shows in the results
+            n_it = 3 + len(calls)
+            r = co.solve(Mo, co.Opts(max_iter=n_it), x0[lo:hi], us0[lo:hi], trace=False)
+            for key in ("xs", "us", "J", "iters", "status"):
+                out[key][:B].copy_(torch.tensor(r[key]))
+            calls.append(id(out))
+        pipe = sharding.GatherPipeline(depth=2, dst=0)
+        job = bench.ShardedSolveJob(solve_into, out_sets, pipe)
+        elapsed = bench.run_steps(job, steps=3, warmup=1, barrier=dist.barrier)
+        assert elapsed > 0 and job.n_steps == 4
+        assert calls == [id(out_sets[i % 2]) for i in range(4)]  # the two sets really alternate
+        if rank == 0:
+            for step in (2, 3):  # the last two steps are still held by the two sets
+                ref = co.solve(Mo, co.Opts(max_iter=3 + step), x0, us0, trace=False)
+                for key in ("xs", "us", "J", "iters", "status"):
+                    g = pipe.result(step % 2, key)
+                    g = g.reshape((world, rows) + tuple(g.shape[1:]))
+                    got = torch.cat([g[r, :sizes[r]] for r in range(world)]).numpy()
+                    assert got.shape == ref[key].shape and np.array_equal(got, ref[key]), (step, key)
+            open(os.path.join(out_dir, "ok"), "w").close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bench_step_wiring(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_job_worker, args=(2, _free_port(), 37, 20, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_sector_granular_factor():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.sector_granular_factor([5] * 16) == 1.0
+    assert bench.sector_granular_factor([10] + [0] * 7) == 8.0
+    assert abs(bench.sector_granular_factor([4, 2] * 4 + [1] * 8) - (32 + 8) / 32.0) < 1e-12
