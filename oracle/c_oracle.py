@@ -281,6 +281,25 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, nthreads=1, trace=True)
     return out
 
 
+def solve_with_step_history(M, O, x0, us_init, **kw):
+    """``solve`` of ONE problem that also returns, per iteration, what boxQP handed back at every time step of
+    that iteration's backward pass: out["hist_qp_result"] [iters, T] (-100 = step not reached) and
+    out["hist_free"] [iters, T, m]."""
+    mi = O.max_iter
+    hq = np.full((mi, M.T), -100, dtype=np.int32)
+    hf = np.zeros((mi, M.T, M.m), dtype=np.int32)
+    L = lib()
+    L.oracle_set_step_history(_pi(hq), _pi(hf), C.c_long(mi))
+    try:
+        out = solve(M, O, np.asarray(x0).reshape(1, M.n), np.asarray(us_init).reshape(1, M.T, M.m), nthreads=1,
+                    trace=True, **kw)
+    finally:
+        L.oracle_set_step_history(None, None, C.c_long(0))
+    it = int(out["iters"][0])
+    out["hist_qp_result"], out["hist_free"] = hq[:it], hf[:it].astype(bool)
+    return out
+
+
 def plant_step(st, u, gravity=9.8, masscart=1.0, masspole=0.1, length=0.5, tau=0.05, math_mode=MATH_DET):
     st, u = _f64(st).reshape(-1, 4), _f64(u).reshape(-1)
     par = _f64([gravity, masscart, masspole, length, tau])

@@ -651,6 +651,18 @@ static long g_qp_capture_cap = 0, g_qp_capture_n = 0;
 void oracle_set_qp_capture(double *buf, long cap) { g_qp_capture = buf; g_qp_capture_cap = cap; g_qp_capture_n = 0; }
 long oracle_get_qp_capture_count(void) { return g_qp_capture_n; }
 
+/* Test hook: per-iteration history of the per-step boxQP outcomes of ONE problem solved with a trace
+ * (single-threaded use): after every iteration's backward pass the result codes [T] and free masks [T*m] are
+ * copied to row `iteration` of these buffers (what boxQP returns at ilqr_core.py:156, step by step). */
+static int *g_hist_qp = NULL, *g_hist_free = NULL;
+static long g_hist_cap = 0;
+void oracle_set_step_history(int *qp_result_hist, int *free_hist, long cap_iters)
+{
+    g_hist_qp = qp_result_hist;
+    g_hist_free = free_hist;
+    g_hist_cap = cap_iters;
+}
+
 /* ------------------------------------------------------- backward pass */
 
 typedef struct {
@@ -948,6 +960,10 @@ static void update_u(const oracle_model *P, const oracle_opts *O, const double *
                 if (O->mu_max != 0.0 && mu >= O->mu_max)
                     break;
             }
+        }
+        if (g_hist_qp && g_hist_free && last_qp_result && last_free && it < g_hist_cap) {
+            memcpy(g_hist_qp + (size_t)it * T, last_qp_result, sizeof(int) * T);
+            memcpy(g_hist_free + (size_t)it * T * m, last_free, sizeof(int) * T * m);
         }
         int j;
         double ratio = NAN, Jnew = 0.0;

@@ -150,9 +150,22 @@ def example_cost(mods, mpc=False):
 
 
 def run_update_u(mods, dynamics, cost, N, x0, us_init, **kw):
-    """One reference update_u call with everything observable recorded."""
-    solver = mods["ilqr_core"].iLQR(dynamics, cost, N)
-    rec = dict(J=[], accepted=[], converged=[], mu=[], delta=[], n_forward=[])
+    """One reference update_u call with everything observable recorded.
+
+    Beyond what the on_iteration callback hands out (ilqr_core.py:342-345), three of the solver's own calls
+    are watched from outside, without touching its code: every ``boxQP`` call of ``_backward_pass`` (:156:
+    the result code and the free mask it returns per time step), the Delta_J1 / Delta_J2 that
+    ``_backward_pass`` returns (:289), and every ``_trajectory_cost`` of the line search (:303), from which
+    the ratio tested at :310 and the improvement tested at :327 are recomputed -- the margins by which the
+    reference's discrete decisions were taken."""
+    core = mods["ilqr_core"]
+    solver = core.iLQR(dynamics, cost, N)
+    m = dynamics.control_dimension
+    scale = kw.get("scale", 0.1)
+    tol = kw.get("tolerance", 1e-4)
+    alphas = 1.1 ** (-np.arange(kw.get("line_search_steps", 30)) ** 2)
+    rec = dict(J=[], accepted=[], converged=[], mu=[], delta=[], n_forward=[], qp_result=[], free=[], dJ1=[],
+               dJ2=[], ratio=[], ratio_margin=[], actual=[])
     calls = [0]
     orig_forward = solver._forward_pass
 
@@ -162,7 +175,33 @@ def run_update_u(mods, dynamics, cost, N, x0, us_init, **kw):
 
     solver._forward_pass = counting_forward
 
+    qp_calls, last_dJ, costs = [], [0.0, 0.0], []
+    orig_boxqp, orig_backward, orig_cost = core.boxQP, solver._backward_pass, solver._trajectory_cost
+
+    def recording_boxqp(H, g, lower, upper, x0_, **opts):
+        out = orig_boxqp(H, g, lower, upper, x0_, **opts)
+        qp_calls.append((int(out[1]), np.array(out[3], dtype=bool).reshape(m).copy()))
+        return out
+
+    def recording_backward(us, xs):
+        del qp_calls[:]  # a retry after LinAlgError starts the sweep again (:287-299)
+        out = orig_backward(us, xs)
+        last_dJ[0], last_dJ[1] = float(out[2]), float(out[3])
+        return out
+
+    def recording_cost(xs, us):
+        J = orig_cost(xs, us)
+        costs.append(float(J))
+        return J
+
+    core.boxQP = recording_boxqp
+    solver._backward_pass = recording_backward
+    solver._trajectory_cost = recording_cost
+    J_prev = [None]
+
     def on_iteration(it, xs, us, J, accepted, converged):
+        if J_prev[0] is None:  # the first recorded cost is that of the initial rollout (:271)
+            J_prev[0] = costs.pop(0)
         rec["J"].append(float(J))
         rec["accepted"].append(bool(accepted))
         rec["converged"].append(bool(converged))
@@ -170,12 +209,38 @@ def run_update_u(mods, dynamics, cost, N, x0, us_init, **kw):
         rec["delta"].append(float(solver.delta_))
         rec["n_forward"].append(calls[0])
         calls[0] = 0
+        # boxQP is called for i = N-1 ... 0 (:127); a non-PD break (:137-140) leaves the earlier steps unvisited
+        qr = np.full(N, -100, dtype=np.int32)
+        fr = np.zeros((N, m), dtype=bool)
+        for c, (result, free) in enumerate(qp_calls):
+            qr[N - 1 - c], fr[N - 1 - c] = result, free
+        rec["qp_result"].append(qr)
+        rec["free"].append(fr)
+        rec["dJ1"].append(last_dJ[0])
+        rec["dJ2"].append(last_dJ[1])
+        # the ratios the line search compared with `scale` (:305-310), one per cost it evaluated
+        ratios = []
+        for a, Jn in zip(alphas, costs):
+            expected = (a * last_dJ[0] + a ** 2 * last_dJ[1]) * -1
+            if expected <= 0:
+                break
+            ratios.append((J_prev[0] - Jn) / expected)
+        rec["ratio"].append(ratios[-1] if ratios else np.nan)
+        finite = [abs(r - scale) for r in ratios if np.isfinite(r)]
+        rec["ratio_margin"].append(min(finite) if finite else np.nan)
+        rec["actual"].append(J_prev[0] - costs[-1] if accepted else np.nan)
+        del costs[:]
+        J_prev[0] = float(J)
 
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        xs, us = solver.update_u(x0, us_init, on_iteration=on_iteration, **kw)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xs, us = solver.update_u(x0, us_init, on_iteration=on_iteration, **kw)
+    finally:
+        core.boxQP = orig_boxqp
     out = dict(x0=x0, us_init=us_init, xs=np.asarray(xs), us=np.asarray(us), k=np.asarray(solver.k_),
-               K=np.asarray(solver.K_), mu_final=float(solver.mu_), delta_final=float(solver.delta_))
+               K=np.asarray(solver.K_), mu_final=float(solver.mu_), delta_final=float(solver.delta_),
+               scale=scale, tolerance=tol)
     for key, val in rec.items():
         out["it_" + key] = np.asarray(val)
     return out

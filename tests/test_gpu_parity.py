@@ -247,6 +247,12 @@ def test_solve_matches_reference_run_fixtures(hip, golden_dir):
         assert np.array_equal(tr["mu"], g[p + "it_mu"]) and np.array_equal(tr["delta"], g[p + "it_delta"])
         assert bool(out["status"][0] == 1) == bool(g[p + "it_converged"][-1])
         np.testing.assert_allclose(out["us"][0].cpu().numpy(), g[p + "us"], rtol=0, atol=1e-8)
+        # the active sets of the reference's own boxQP calls (ilqr_core.py:156), per iteration: steps with a
+        # clamped control, and the step of a non-PD break
+        reached = g[p + "it_qp_result"] != -100
+        assert np.array_equal(tr["n_clamped"], (reached & ~g[p + "it_free"][:, :, 0]).sum(axis=1))
+        assert np.array_equal(tr["stopped_at"],
+                              np.where(reached.all(axis=1), -1, reached.shape[1] - 1 - reached[:, ::-1].sum(axis=1)))
 
 
 def test_boxqp_batched(hip, golden_dir):

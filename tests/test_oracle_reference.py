@@ -49,6 +49,37 @@ def test_update_u_matches_reference_run(solve_vec, tag, math_mode):
         np.testing.assert_allclose(out["K"][0], g[p + "K"], rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("tag", ["oracle", "sympy"])
+def test_boxqp_outcomes_per_step_and_decision_margins_match_reference_run(solve_vec, tag):
+    """What the reference's boxQP returned at EVERY time step of EVERY backward pass (ilqr_core.py:156: result
+    code and free mask, recorded by watching the call from outside) against the oracle's, plus the two
+    quantities its discrete decisions were taken on: the line-search ratio (:310) and the accepted
+    improvement (:327).  The recorded margins show how far the run stayed from a tie."""
+    g = solve_vec
+    M = co.cartpole_model(math_mode=co.MATH_LIBM)
+    n_codes = set()
+    for i in range(int(g["n_problems"])):
+        p = "%s_p%d_" % (tag, i)
+        out = co.solve_with_step_history(M, co.Opts(max_iter=int(g[p + "max_iter"])), g[p + "x0"], g[p + "us_init"])
+        it = int(out["iters"][0])
+        assert it == len(g[p + "it_J"])
+        assert np.array_equal(out["hist_qp_result"], g[p + "it_qp_result"]), (tag, i)
+        assert np.array_equal(out["hist_free"], g[p + "it_free"]), (tag, i)
+        reached = g[p + "it_qp_result"] != -100
+        n_clamped_ref = (reached & ~g[p + "it_free"][:, :, 0]).sum(axis=1)
+        assert np.array_equal(out["trace"]["n_clamped"][0, :it], n_clamped_ref)
+        first_unreached = np.where(reached.all(axis=1), -1, reached.shape[1] - 1 - reached[:, ::-1].sum(axis=1))
+        assert np.array_equal(out["trace"]["stopped_at"][0, :it], first_unreached)
+        n_codes |= set(np.unique(g[p + "it_qp_result"]))
+        # decisions: same ratio and improvement as the reference computed, and no decision near a tie
+        np.testing.assert_allclose(out["trace"]["ratio"][0, :it], g[p + "it_ratio"], rtol=1e-6, equal_nan=True)
+        scale, tol = float(g[p + "scale"]), float(g[p + "tolerance"])
+        assert np.nanmin(g[p + "it_ratio_margin"]) > 1e-3 * scale
+        acc = g[p + "it_accepted"]
+        assert np.nanmin(np.abs(g[p + "it_actual"][acc] - tol)) > 1e-3 * tol
+    assert {2, 5, 6} <= n_codes  # line search exhausted, small gradient, all clamped: all occur
+
+
 def pathqr_model(g, math_mode):
     N = int(g["N"])
     return co.Model(co.MODEL_CARTPOLE, 5, 1, N, co.COST_PATHQR, math_mode, True, dt=0.05, Q=g["Q"], R=g["R"],
