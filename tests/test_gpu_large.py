@@ -244,3 +244,31 @@ def test_large_full_size_batch_properties(hip):
     for key in ("us", "xs", "J", "K"):
         assert torch.equal(part[key], out[key][lo:hi]), key
     assert np.array_equal(part["iters"].cpu().numpy(), iters[lo:hi])
+
+
+@pytest.mark.parametrize("T,seed", [(25, 17), (60, 18)])
+def test_large_backward_pass_is_the_riccati_recursion_and_one_full_step_is_optimal(hip, T, seed):
+    """A known answer independent of the oracle and of the reference's code (tests/lq_known_answer.py): with
+    c = 0 the synthetic model is linear; with mu = 0 and limits that never bind, one backward pass of the
+    device code must give the textbook Riccati gains (1e-9), one alpha = 1 forward pass the optimum of the
+    linear-quadratic problem as numpy's dense solve finds it (1e-9 on controls, 1e-10 on the cost), and
+    -(Delta_J1 + Delta_J2) the true improvement."""
+    import lq_known_answer as lq
+    p = lq.problem(T=T, seed=seed)
+    big = 1e6
+    M = hip.LargeModel(T, p["A"], p["B"], np.zeros((32, 32)), p["Q"], p["R"], p["Qf"], None, None, np.full(8, -big),
+                       np.full(8, big), dt=p["dt"], sig_c=0.0, x_path=p["g"], u_path=p["h"])
+    x0, us = dev(p["x0"][None]), dev(p["us_start"][None])
+    xs, J0 = hip.large_rollout_cost(M, x0, us)
+    assert abs(float(J0[0]) - lq.cost(p, lq.rollout(p, p["us_start"]), p["us_start"])) <= 1e-12 * float(J0[0])
+    bw = hip.large_backward(M, hip.Opts(), xs, us, dev(np.zeros(1)))
+    info = bw["info"].cpu().numpy()
+    assert info[0, 0] == -1 and info[3, 0] == 0 and (bw["qp_result"].cpu().numpy() == 5).all()
+    J_new, xs_new, us_new = hip.large_forward_ls(M, [1.0], xs, us, bw["k"], bw["K"], store_idx=0)
+    dJ = bw["dJ"].cpu().numpy()
+    lq.check(p, bw["k"][0].cpu().numpy(), bw["K"][0].cpu().numpy(), dJ[0, 0], dJ[1, 0], us_new[0].cpu().numpy(),
+             float(J_new[0, 0]))
+    # the whole solve ends on the same optimum
+    out = hip.large_solve(M, hip.Opts(max_iter=50, tol=1e-12), x0, us)
+    _, _, J_opt = lq.dense_optimum(p)
+    assert abs(float(out["J"][0]) - J_opt) <= 1e-9 * J_opt
