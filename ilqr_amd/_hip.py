@@ -69,7 +69,7 @@ EXPORTS = (
     "ilqr_boxqp_batched", "ilqr_solve_workspace_bytes", "ilqr_solve_batched",
     "ilqr_solve_chunked_workspace_bytes", "ilqr_solve_batched_chunked", "ilqr_solve_batched_static",
     "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
-    "ilqr_large_rollout_cost", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
+    "ilqr_large_rollout_cost", "ilqr_large_deriv", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
     "ilqr_large_solve_batched", "ilqr_large_debug_profile", "ilqr_cartpole_mpc_advance",
 )
 
@@ -495,6 +495,24 @@ def large_rollout_cost(M, x0, us):
     check(lib().ilqr_large_rollout_cost(C.byref(M.c), C.c_int64(B), _ptr(_req(x0, torch.float64)),
                                         _ptr(_req(us, torch.float64)), _ptr(xs), _ptr(J), _stream()))
     return xs, J
+
+
+def large_deriv(M, xs, us, out=None):
+    """ilqr_large_deriv: the derivative tensors of every (problem, step) in the reference's layout."""
+    import torch
+    B, dev = xs.shape[0], xs.device
+    T, n, m = M.T, M.n, M.m
+    shapes = dict(fx=(B, T, n, n), fu=(B, T, n, m), lx=(B, T, n), lu=(B, T, m), lxx=(B, T, n, n), luu=(B, T, m, m),
+                  lux=(B, T, m, n), lxT=(B, n), lxxT=(B, n, n))
+    if out is None:
+        out = {k: torch.empty(s, dtype=torch.float64, device=dev) for k, s in shapes.items()}
+    d = DerivC()
+    for k, s in shapes.items():
+        assert tuple(out[k].shape) == s
+        setattr(d, k, _req(out[k], torch.float64).data_ptr())
+    check(lib().ilqr_large_deriv(C.byref(M.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
+                                 _ptr(_req(us, torch.float64)), C.byref(d), _stream()))
+    return out
 
 
 def large_backward(M, O, xs, us, mu, want_masks=True):

@@ -1310,6 +1310,91 @@ __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int
     }
 }
 
+// ------------------------------------------------------- derivative tensor stream
+
+// The tensors _compute_Q_terms asks the model and the cost for (ilqr_core.py:189-198) at every (problem, step),
+// written as dense streams in the reference's layout: f_x [B,T,n,n], f_u [B,T,n,m], l_x [B,T,n], l_u [B,T,m],
+// l_xx [B,T,n,n], l_uu [B,T,m,m], l_ux [B,T,m,n], terminal l_x [B,n], l_xx [B,n,n]: 21.3 KB per (problem,
+// step), a pure HBM write stream.  One workgroup handles DS consecutive steps of one problem: the 32-term
+// chains (W x, and x_diff^T (Q + Q^T)) run on 32 lanes per step out of LDS copies of W and Q + Q^T, then all
+// 256 threads write the element-wise parts, 256 consecutive doubles per store.
+//   f_x = I + dt (A + c diag(phi'(W x)) W),  phi'(z) = 1 / ((1 + z^2) sqrt(1 + z^2));   f_u = dt B.
+constexpr int DS = 8; // steps per workgroup
+
+template <bool PATH>
+__global__ __launch_bounds__(256) void k_large_deriv(LargeP P, int64_t B, const double* __restrict__ xs,
+                                                     const double* __restrict__ us, ilqr_deriv_bm_t o)
+{
+    __shared__ double s_W[LN][LN + 1], s_QQ[LN][LN + 1], s_RR[LM][LM];
+    __shared__ double s_x[DS][LN], s_g[DS][LN];
+    const int T = P.T;
+    const int chunks = (T + 1 + DS - 1) / DS; // step T (terminal) included
+    const int64_t b = blockIdx.x / chunks;
+    const int t0 = (int)(blockIdx.x % chunks) * DS;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < LN * LN; e += 256) {
+        int i = e / LN, j = e % LN;
+        s_W[i][j] = P.W[e];
+        s_QQ[i][j] = P.Q[i * LN + j] + P.Q[j * LN + i]; // (Q + Q^T)[i][j], ilqr_cost.py:526
+    }
+    if (tid < LM * LM)
+        s_RR[tid / LM][tid % LM] = P.R[tid] + P.R[(tid % LM) * LM + tid / LM];
+    {
+        int s = tid >> 5, i = tid & 31, t = t0 + s;
+        s_x[s][i] = t <= T ? xs[(b * (T + 1) + t) * LN + i] : 0.0;
+    }
+    __syncthreads();
+    {   // 32-term chains, one (step, row) per thread
+        const int s = tid >> 5, i = tid & 31, t = t0 + s;
+        if (t < T) {
+            double z = s_W[i][0] * s_x[s][0];
+#pragma unroll 8
+            for (int j = 1; j < LN; ++j)
+                z = fma(s_W[i][j], s_x[s][j], z);
+            double sq = 1.0 + z * z;
+            s_g[s][i] = P.sig_c * (1.0 / (sq * sqrt(sq)));
+            // l_x[i] = sum_a x_diff[a] (Q + Q^T)[a][i]   (ilqr_cost.py:555-569)
+            const double* xg = PATH ? P.xg + (int64_t)t * LN : P.xg;
+            double acc = (s_x[s][0] - xg[0]) * s_QQ[0][i];
+#pragma unroll 8
+            for (int a = 1; a < LN; ++a)
+                acc = fma(s_x[s][a] - xg[a], s_QQ[a][i], acc);
+            o.lx[(b * T + t) * LN + i] = acc;
+            if (i < LM) { // l_u[i] = sum_a u_diff[a] (R + R^T)[a][i]   (:571-587)
+                const double* ug = PATH ? P.ug + (int64_t)t * LM : P.ug;
+                const double* u = us + (b * T + t) * LM;
+                double au = (u[0] - ug[0]) * s_RR[0][i];
+#pragma unroll
+                for (int a = 1; a < LM; ++a)
+                    au = fma(u[a] - ug[a], s_RR[a][i], au);
+                o.lu[(b * T + t) * LM + i] = au;
+            }
+        } else if (t == T) { // terminal l_x, l_xx (ilqr_core.py:120-121), Q_terminal read from memory
+            const double* xg = PATH ? P.xg + (int64_t)T * LN : P.xg;
+            double acc = (s_x[s][0] - xg[0]) * (P.Qt[0 * LN + i] + P.Qt[i * LN + 0]);
+            for (int a = 1; a < LN; ++a)
+                acc = fma(s_x[s][a] - xg[a], P.Qt[a * LN + i] + P.Qt[i * LN + a], acc);
+            o.lxT[b * LN + i] = acc;
+            for (int a = 0; a < LN; ++a)
+                o.lxxT[(b * LN + a) * LN + i] = P.Qt[a * LN + i] + P.Qt[i * LN + a];
+        }
+    }
+    __syncthreads();
+    const int ns = (T - t0) < DS ? (T - t0) : DS; // steps t < T of this chunk
+    for (int s = 0; s < ns; ++s) {
+        const int64_t bt = b * T + t0 + s;
+        for (int e = tid; e < LN * LN; e += 256) {
+            int i = e >> 5, j = e & 31;
+            o.fx[bt * LN * LN + e] = (i == j ? 1.0 : 0.0) + P.dt * (P.A[e] + s_g[s][i] * s_W[i][j]);
+            o.lxx[bt * LN * LN + e] = s_QQ[i][j];
+        }
+        o.fu[bt * LN * LM + tid] = P.dt * P.B[tid];
+        o.lux[bt * LM * LN + tid] = 0.0;
+        if (tid < LM * LM)
+            o.luu[bt * LM * LM + tid] = s_RR[tid / LM][tid % LM];
+    }
+}
+
 // ------------------------------------------------------------------ host side
 
 int large_check(const ilqr_large_model* m)
@@ -1388,6 +1473,26 @@ int ilqr_large_rollout_cost(const ilqr_large_model* model, int64_t B, const doub
         hipLaunchKernelGGL(k_large_rollout_cost<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), B, x0, us,
                            xs, J);
     }
+    return lrc(hipGetLastError());
+}
+
+int ilqr_large_deriv(const ilqr_large_model* model, int64_t B, const double* xs, const double* us,
+                     const ilqr_deriv_bm_t* out, void* stream)
+{
+    int rc = large_check(model);
+    if (rc != ILQR_OK)
+        return rc;
+    if (B < 1 || !xs || !us || !out || !out->fx || !out->fu || !out->lx || !out->lu || !out->lxx || !out->luu ||
+        !out->lux || !out->lxT || !out->lxxT)
+        return ILQR_ERR_ARG;
+    const int64_t chunks = (model->T + 1 + DS - 1) / DS;
+    if (B * chunks > 0x7fffffffLL)
+        return ILQR_ERR_ARG;
+    dim3 grid((unsigned)(B * chunks));
+    if (model->cost_kind == ILQR_COST_PATH_QR)
+        hipLaunchKernelGGL(k_large_deriv<true>, grid, dim3(256), 0, ls(stream), large_fill(model), B, xs, us, *out);
+    else
+        hipLaunchKernelGGL(k_large_deriv<false>, grid, dim3(256), 0, ls(stream), large_fill(model), B, xs, us, *out);
     return lrc(hipGetLastError());
 }
 

@@ -272,6 +272,17 @@ typedef struct ilqr_large_model {
 int ilqr_large_rollout_cost(const ilqr_large_model* model, int64_t B, const double* x0, const double* us,
                             double* xs, double* J, void* stream);
 
+/* Dynamics.f_x / f_u (ilqr_dynamics.py:498-524) and Cost.l_x, l_u, l_xx, l_uu, l_ux (ilqr_cost.py:555-632) of
+ * the synthetic model for every (problem, step), plus the terminal l_x, l_xx: the tensors _compute_Q_terms
+ * (ilqr_core.py:189-198) asks for, as dense streams in the reference's layout (the struct of ilqr_deriv_bm,
+ * here batch outermost):
+ *   fx [B,T,n,n]  fu [B,T,n,m]  lx [B,T,n]  lu [B,T,m]  lxx [B,T,n,n]  luu [B,T,m,m]  lux [B,T,m,n]
+ *   lxT [B,n]  lxxT [B,n,n]            (21.3 KB per problem and step).
+ * xs [B,T+1,n], us [B,T,m].  The solve kernels evaluate these in registers instead; this entry point exists
+ * for callers that want the tensors themselves and to measure derivative streaming. */
+int ilqr_large_deriv(const ilqr_large_model* model, int64_t B, const double* xs, const double* us,
+                     const ilqr_deriv_bm_t* out, void* stream);
+
 /* iLQR._backward_pass (ilqr_core.py:109-228) with boxQP: xs, us, mu [B] -> k [B,T,m],
  * K [B,T,m,n], dJ [2,B], info [5,B] (as ilqr_backward_bm with ld = B); optional
  * qp_result [B,T] and free_mask [B,T,m]. */

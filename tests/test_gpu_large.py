@@ -272,3 +272,37 @@ def test_large_backward_pass_is_the_riccati_recursion_and_one_full_step_is_optim
     out = hip.large_solve(M, hip.Opts(max_iter=50, tol=1e-12), x0, us)
     _, _, J_opt = lq.dense_optimum(p)
     assert abs(float(out["J"][0]) - J_opt) <= 1e-9 * J_opt
+
+
+@pytest.mark.parametrize("path", [False, True])
+def test_large_derivative_streams_bit_exact(hip, path):
+    """ilqr_large_deriv: f_x, f_u, l_x, l_u, l_xx, l_uu, l_ux per (problem, step) and the terminal l_x, l_xx of
+    the synthetic model, against the oracle's derivative evaluation, with QRCost and with PathQRCost; T is
+    not a multiple of the kernel's steps-per-workgroup."""
+    T, B = 21, 5
+    Mq = co.synthetic_model(T=T)
+    r = np.random.RandomState(33)
+    Qf = Mq.Q + 0.1 * r.randn(32, 32)  # full, non-symmetric cost matrices
+    Rf = Mq.R + 0.01 * r.randn(8, 8)
+    Qtf = Mq.Qt + 0.1 * r.randn(32, 32)
+    x_path, u_path = 0.3 * r.randn(T + 1, 32), 0.2 * r.randn(T, 8)
+    if path:
+        Mo = co.Model(co.MODEL_SIGMOID, 32, 8, T, co.COST_PATHQR, co.MATH_DET, True, dt=Mq.dt, A=Mq.A, B=Mq.B, W=Mq.W,
+                      sig_c=Mq.sig_c, Q=Qf, R=Rf, Q_terminal=Qtf, x_goal=x_path, u_goal=u_path, lower=Mq.lower,
+                      upper=Mq.upper)
+        M = hip.LargeModel(T, Mq.A, Mq.B, Mq.W, Qf, Rf, Qtf, None, None, Mq.lower, Mq.upper, dt=Mq.dt,
+                           sig_c=Mq.sig_c, x_path=x_path, u_path=u_path)
+    else:
+        xg, ug = 0.1 * r.randn(32), 0.1 * r.randn(8)
+        Mo = co.Model(co.MODEL_SIGMOID, 32, 8, T, co.COST_QR, co.MATH_DET, True, dt=Mq.dt, A=Mq.A, B=Mq.B, W=Mq.W,
+                      sig_c=Mq.sig_c, Q=Qf, R=Rf, Q_terminal=Qtf, x_goal=xg, u_goal=ug, lower=Mq.lower, upper=Mq.upper)
+        M = hip.LargeModel(T, Mq.A, Mq.B, Mq.W, Qf, Rf, Qtf, xg, ug, Mq.lower, Mq.upper, dt=Mq.dt, sig_c=Mq.sig_c)
+    x0, us = co.synthetic_batch(B, T=T, seed_x=51, seed_u=52)
+    us *= 2.0
+    xs, _ = co.rollout_cost(Mo, x0, us)
+    out = hip.large_deriv(M, dev(xs), dev(us))
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = co.derivatives(Mo, xs[b], us[b])
+        for key in ("fx", "fu", "lx", "lu", "lxx", "luu", "lux", "lxT", "lxxT"):
+            assert eq(out[key][b].cpu().numpy(), ref[key]), (b, key)
