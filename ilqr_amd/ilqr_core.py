@@ -105,12 +105,24 @@ class iLQR(BaseTrajOptimizer):
             return user_model.UserModel(d.lib, self.N, d.params, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal,
                                         self.lower_bound, self.upper_bound)
         if d.device_model == "sigmoid32":
-            if isinstance(c, PathQRCost):
-                return _hip.LargeModel(self.N, d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, None, None, self.lower_bound,
-                                       self.upper_bound, dt=d.tau, sig_c=d.sig_c, device=self._device(),
-                                       x_path=c.x_path, u_path=c.u_path)
-            return _hip.LargeModel(self.N, d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal, self.lower_bound,
-                                   self.upper_bound, dt=d.tau, sig_c=d.sig_c, device=self._device())
+            # the device copy of the model (ten uploads) is kept while nothing it was built from has changed
+            path = isinstance(c, PathQRCost)
+            goals = (c.x_path, c.u_path) if path else (c.x_goal, c.u_goal)
+            sig = (self.N, float(d.tau), float(d.sig_c), str(self._device()), path) + tuple(
+                np.ascontiguousarray(a, dtype=np.float64).tobytes()
+                for a in (d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, self.lower_bound, self.upper_bound) + goals)
+            cached = getattr(self, "_large_model_cache", None)
+            if cached is not None and cached[0] == sig:
+                return cached[1]
+            if path:
+                M = _hip.LargeModel(self.N, d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, None, None, self.lower_bound,
+                                    self.upper_bound, dt=d.tau, sig_c=d.sig_c, device=self._device(),
+                                    x_path=c.x_path, u_path=c.u_path)
+            else:
+                M = _hip.LargeModel(self.N, d.A, d.B, d.W, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal,
+                                    self.lower_bound, self.upper_bound, dt=d.tau, sig_c=d.sig_c, device=self._device())
+            self._large_model_cache = (sig, M)
+            return M
         kw = dict(dt=d.tau, mc=d.masscart, mp=d.masspole, l=d.length, g=d.gravity)
         if isinstance(c, PathQRCost):
             x_path, u_path = c.device_paths(self._device())
@@ -205,7 +217,9 @@ class iLQR(BaseTrajOptimizer):
 
         if on_iteration is None:
             if isinstance(M, _hip.LargeModel):  # one problem per wavefront: a finished problem frees its wave
-                res = self._solve(M, _hip.Opts(max_iter=n_interations, **kw), x0_d, us_d, delta=delta, k=k, K=K)
+                res = self._solve(M, _hip.Opts(max_iter=n_interations, **kw), x0_d, us_d, delta=delta, k=k, K=K,
+                                  workspace=getattr(self, "_large_workspace", None))
+                self._large_workspace = res["workspace"]  # kept for the next call (re-solves of a closed loop)
             else:  # lane per problem: very large batches drop their finished problems between chunks of iterations
                 from . import compaction
                 res = compaction.solve_auto(lambda M_, O_, *a, **b: self._solve(M_, O_, *a, **b), M, kw, n_interations,

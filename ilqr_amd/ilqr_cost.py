@@ -134,13 +134,27 @@ class PathQRCost(Cost):
         super().__init__()
 
     def device_paths(self, device):
-        """x_path, u_path as fp64 tensors on ``device`` (uploaded once per device)."""
+        """x_path, u_path as fp64 tensors on ``device``.  The tensors are allocated once per device and keep
+        their addresses; their CONTENTS follow the host arrays: a caller that shifts ``x_path`` / ``u_path``
+        between two ``update_u`` calls (receding-horizon tracking, ilqr_core.py:437-438) gets the new path on
+        the device at the next call."""
         import torch
         key = str(device)
-        if key not in self._device_paths:
-            self._device_paths[key] = (torch.tensor(self.x_path, device=device).contiguous(),
-                                       torch.tensor(self.u_path, device=device).contiguous())
-        return self._device_paths[key]
+        x_h = np.ascontiguousarray(self.x_path, dtype=np.float64)
+        u_h = np.ascontiguousarray(self.u_path, dtype=np.float64)
+        entry = self._device_paths.get(key)
+        if entry is None or entry[2].shape != x_h.shape or entry[3].shape != u_h.shape:
+            entry = [torch.tensor(x_h, device=device).contiguous(), torch.tensor(u_h, device=device).contiguous(),
+                     x_h.copy(), u_h.copy()]
+            self._device_paths[key] = entry
+        else:
+            if not np.array_equal(entry[2], x_h):
+                entry[0].copy_(torch.from_numpy(x_h))
+                entry[2] = x_h.copy()
+            if not np.array_equal(entry[3], u_h):
+                entry[1].copy_(torch.from_numpy(u_h))
+                entry[3] = u_h.copy()
+        return entry[0], entry[1]
 
     def l(self, x, u, i, terminal=False):
         Q = self.Q_terminal if terminal else self.Q

@@ -283,6 +283,18 @@ def test_pathqrcost_through_the_solver_api(golden_dir):
     assert eq(xs_b, ref["xs"]) and eq(us_b, ref["us"])
     with pytest.raises(ValueError):
         iLQR(dyn, cost, N + 1)  # the path is too short for this horizon
+    # A caller that moves the path between two calls (receding-horizon tracking shifts the goals,
+    # ilqr_core.py:437-438) must get the new path on the device: same solver object, path shifted one step.
+    s2 = iLQR(dyn, cost, N)
+    s2.update_u(x0, us0, n_iterations=5)
+    cost.x_path = np.concatenate([cost.x_path[1:], cost.x_path[-1:]])
+    cost.u_path = np.concatenate([cost.u_path[1:], cost.u_path[-1:]])
+    Mo2 = co.Model(co.MODEL_CARTPOLE, 5, 1, N, co.COST_PATHQR, co.MATH_DET, True, dt=0.05, Q=g["Q"], R=g["R"],
+                   Q_terminal=g["Qt"], x_goal=cost.x_path, u_goal=cost.u_path, lower=[-5.0], upper=[5.0])
+    ref2 = co.solve(Mo2, co.Opts(max_iter=12), x0, us0, nthreads=8, trace=False)
+    xs_2, us_2 = iLQR(dyn, cost, N).update_u(x0, us0, n_iterations=12)   # fresh solver state, same cost object
+    assert eq(xs_2, ref2["xs"]) and eq(us_2, ref2["us"])
+    assert not eq(us_2, ref["us"])
 
 
 def test_boxqp_api(golden_dir):

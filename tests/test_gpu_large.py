@@ -145,6 +145,12 @@ def test_large_model_through_the_solver_api(hip):
     it_n = int(ref["iters"][0])
     assert eq(us1, ref["us"][0]) and len(log) == it_n
     assert eq([l[1] for l in log], ref["trace"]["J"][0, :it_n])
+    # the device copy of the model is reused while nothing changes, and rebuilt when the cost does
+    M1 = s._model()
+    assert s._model() is M1
+    cost.R = 2.0 * cost.R
+    cost._R_plus_R_T = cost.R + cost.R.T
+    assert s._model() is not M1
     # host-side f / f_x of the mirror class agree with the oracle's model
     f, fx, fu = co.dynamics(Mo, x0[0], us0[0, 0])
     np.testing.assert_allclose(dyn.f(x0[0], us0[0, 0], 0), f[0], rtol=1e-13, atol=1e-13)

@@ -266,3 +266,27 @@ def test_user_model_chunked_solve_with_compaction(hip):
         assert torch.equal(one[key], chunked[key]), key
     it = one["iters"].cpu().numpy()
     assert (it < 40).any() and it.max() > 5
+
+
+def test_user_model_compaction_just_above_the_threshold(hip):
+    """A user-model batch between 49152 and 65535 problems: when its running set falls to between half the
+    batch and 32768 problems (here after 6 iterations: 32730 of 49852), the launch uses 32 problems per
+    wavefront and needs a LARGER workspace than the full batch did; the workspace handed from launch to
+    launch must be re-sized, and the results must be those of the single launch."""
+    import ctypes
+    from ilqr_amd import compaction, user_model as um
+    T, B = 12, 49152 + 700
+    Mo = pendulum(T)
+    x0, us0 = pendulum_batch(B, T, seed=171)
+    M = um.UserModel(um.load("pendulum_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, None, Mo.lower, Mo.upper)
+
+    def need(n):
+        return int(M.lib.ilqr_user_workspace_bytes(ctypes.byref(M.c), ctypes.c_int64(n)))
+    one = um.solve(M, hip.Opts(max_iter=24), dev(x0), dev(us0))
+    it = one["iters"].cpu().numpy()
+    running = [int((it > c).sum()) for c in range(0, 24, 2)]  # at the chunk boundaries
+    assert any(n <= 32768 and need(n) > need(B) for n in running), running
+    chunked = compaction.solve_compacting(um.solve, M, {}, 24, dev(x0), dev(us0), chunk=2)
+    torch.cuda.synchronize()
+    for key in ("xs", "us", "J", "mu", "delta", "iters", "status", "k", "K"):
+        assert torch.equal(one[key], chunked[key]), key
