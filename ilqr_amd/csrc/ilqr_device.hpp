@@ -897,6 +897,39 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
     out.n_backtrack = (act0 ? n0 : 0) + (exh1 ? O.n_exhaust : 0);
 }
 
+// The outcome of boxqp1 on its most common path, by the shortest chain of dependent operations: pass 0 jumps
+// to trip t_j and accepts, pass 1 accepts the full Newton step, pass 2 ends on a termination test.  Same
+// expressions as boxqp1 (a compiler merges the two), none of its checks: the caller must compare with boxqp1.
+__device__ __forceinline__ void boxqp1_guess(const QPOptsP& O, const double* tab, double H, double rsqrtH, double g,
+                                             double lo, double hi, double x0, double& x_out, bool& free_out)
+{
+    const double xa = fmax(lo, fmin(hi, x0));
+    const double rhs = g + 0.0;
+    const double grad0 = g + H * xa;
+    const double search0 = rhs * -1 - xa;
+    double G = fabs(grad0), as = fabs(search0);
+    double gerr = 5e-16 * (fabs(g) + fabs(H * xa));
+    bool descent = (((search0 > 0.0) & (grad0 < 0.0)) | ((search0 < 0.0) & (grad0 > 0.0))) & (G > 4.0 * gerr);
+    float Gf = (float)G, Hf = (float)H, cf = (float)(1.0 - O.armijo);
+    float cg = cf * Gf;
+    float up = (cg + __builtin_amdgcn_sqrtf(cg * cg + (float)(2e-10 * O.armijo) * Hf)) * __builtin_amdgcn_rcpf(Hf);
+    float U = fmaxf(up, 1e-10f * __builtin_amdgcn_rcpf(Gf));
+    float tf = __builtin_amdgcn_logf(U * __builtin_amdgcn_rcpf((float)as)) * O.inv_log2_dec;
+    tf = fminf(fmaxf(tf, 0.0f), 1.0e6f);
+    int tj = (int)tf + 1;
+    tj = tj < O.tab_n ? tj : O.tab_n - 1;
+    bool try_jump = descent & (tj >= 2);
+    tj = try_jump ? tj : 1;
+    const double sj = tab[tj];
+    const double xb = fmax(lo, fmin(hi, xa + (try_jump ? sj : 1.0) * search0));
+    const double search1 = ((rhs * rsqrtH) * rsqrtH) * -1 - xb;
+    const double xc = fmax(lo, fmin(hi, xb + 1.0 * search1));
+    const double grad2 = g + H * xc;
+    const bool cl2 = ((xc == lo) & (grad2 > 0.0)) | ((xc == hi) & (grad2 < 0.0));
+    x_out = xc;
+    free_out = !cl2;
+}
+
 // ---- backward step ----------------------------------------------------------
 
 struct BwAcc {          // running state of one backward sweep

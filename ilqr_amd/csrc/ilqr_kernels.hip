@@ -12,6 +12,7 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/ilqr_hip.h"
 #include "ilqr_device.hpp"
@@ -626,6 +627,382 @@ __global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP Cp, A
     Jnew[(int64_t)ai * ld + b] = forward_rollout<STORE>(P, C, T, ld, b, xs, us, k, K, al.a[ai], xo, uo);
 }
 
+// ------------------------------------------- backward pass shared by two wavefronts
+//
+// Up to 32768 problems every wavefront has a SIMD to itself and the solve takes as long as ONE wavefront
+// needs for its instruction stream; most of that is the backward sweep's serial chain
+//     V  ->  Q_uu, Q_u  ->  Cholesky, boxQP  ->  k, K  ->  V of the step before,
+// of which the boxQP's three passes alone are ~450 instructions that depend on one another (a dependent fp64
+// operation issues every ~8 cycles).  With SIMDs to spare the sweep is cut between two wavefronts that hold
+// the same problems lane for lane and hand a few numbers per lane back and forth through LDS:
+//   master: from rows 1 and 4 of V (the non-zero rows of f_u) Q_uu and Q_u, the PD test, Cholesky, boxQP,
+//           Delta_J (the part of ilqr_core.py:137-156, :175-176 that the rest of the step waits for);
+//   helper: Jacobian, Q_x, Q_xx, Q_ux (:206-212), then K and the value update (:157-169).
+// Two things take work out of the chain itself.
+//  * The master's next step needs six numbers of the value update only (entries (1,1), (1,4), (4,1), (4,4)
+//    of V_xx and V_x[1], V_x[4]); the helper forms and hands over those first and completes the update while
+//    the master is in its boxQP again.
+//  * The boxQP ends on its common path (jump in pass 0, full Newton step in pass 1, a termination test in
+//    pass 2) in almost every call, and the outcome of that path follows from ~35 dependent operations
+//    (boxqp1_guess).  The master hands that GUESS to the helper at once and only then runs boxqp1 in full,
+//    which takes as long as the helper needs for the six numbers.  If the verified outcome differs from the
+//    guess in any lane (wave-uniform flag), the helper recomputes its six numbers from the verified outcome
+//    in one extra hand-over; results therefore never depend on a guess.
+// Hand-overs per step: #2 master -> helper (the guess), #1 helper -> master (six numbers + f_u of the step
+// before + the master's verdict on the previous guess), #1b only after a wrong guess.  Every number is
+// computed by the expression the one-wavefront sweep uses, hence the same bits.
+struct PairX {
+    double v[5][64];          // helper -> master, for the master's next step: Q_uu, Q_u, its Cholesky factor L, 1 / L, the warm start
+    int st[64];               // ... and BW_OK / BW_NOT_PD / BW_LINALG (the PD test of ilqr_core.py:137-140)
+    double kk[64], rdiag[64]; // master -> helper, guessed: boxQP solution, reciprocal of the 1x1 factor
+    int free_[64], ok[64];    // guessed free mask; ok = 0: the lane's sweep has ended (not PD / non-finite Q_uu), never a guess
+    double kk2[64], rdiag2[64]; // master -> helper, verified (read only after a wrong guess)
+    int free2[64];
+    int fix;                  // the guess of the step just verified was wrong in some lane
+    double mu[64];            // per sweep, master -> helper
+    int act[64], cur[64], gnew[64];
+    int cmd;                  // 1 = run a sweep, 0 = leave
+};
+
+// LDS hand-over between the two wavefronts of a pair: waits for LDS only, so global loads issued ahead
+// of the barrier stay in flight across it.
+__device__ __forceinline__ void pair_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+#ifdef ILQR_PAIR_PROF // diagnostic build only: shader clocks of the two halves of the shared backward sweep
+static __device__ unsigned long long g_pair_prof[2][8];
+#define PP_DECL unsigned long long pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PP_T(var) const long long var = __builtin_amdgcn_s_memtime()
+#define PP_ADD(role, slot, a, bq) pp_acc[slot] += (unsigned long long)((bq) - (a))
+#define PP_COUNT(role, slot) pp_acc[slot] += 1ull
+#define PP_FLUSH(role)                                                                \
+    if (lane == 0 && blockIdx.x == 0)                                                  \
+        for (int q_ = 0; q_ < 8; ++q_)                                                 \
+            atomicAdd(&g_pair_prof[role][q_], pp_acc[q_])
+#else
+#define PP_DECL
+#define PP_T(var)
+#define PP_ADD(role, slot, a, bq)
+#define PP_COUNT(role, slot)
+#define PP_FLUSH(role)
+#endif
+
+// Master half of one backward sweep.  act: the lane takes part (its problem still needs this backward pass).
+// S receives Delta_J and the boxQP counters; k [T, ld] is written for the lanes that take part (zeros where
+// the sweep did not reach).
+template <class Cost>
+__device__ __forceinline__ int pair_master_sweep(const Cost& C, const QPOptsP& QO, const double* qp_tab,
+                                                 const BoundsP& bd, int T, int64_t ld, int64_t b, PairX& X, int lane,
+                                                 bool act, const double* __restrict__ us, double mu,
+                                                 double* __restrict__ k, BwAcc& S, int& stopped_at)
+{
+    S.dJ1 = 0.0;
+    S.dJ2 = 0.0;
+    S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
+    stopped_at = -1;
+    int rc = BW_OK;
+    double u = us[(int64_t)(T - 1) * ld + b];
+    PP_DECL;
+    if (lane == 0)
+        X.fix = 0;
+    bool fix = false; // wave-uniform: the guess of the step before was wrong in some lane
+    for (int i = T - 1; i >= 0; --i) {
+        const int ip = i > 0 ? i - 1 : 0;
+        const double up = us[(int64_t)ip * ld + b]; // operand of the step before, loaded ahead
+        PP_T(t0);
+        pair_barrier(); // #1: the helper's numbers of step i are in X (formed from the guess of step i+1) ...
+        if (fix) { // ... which was wrong: the helper is forming them again from the verified outcome
+            pair_barrier(); // #1b
+            if (lane == 0)
+                X.fix = 0;
+            fix = false;
+        }
+        PP_T(t1);
+        PP_ADD(0, 0, t0, t1);
+        const double Quu = X.v[0][lane], Qu = X.v[1][lane], L = X.v[2][lane], rL = X.v[3][lane], k0 = X.v[4][lane];
+        const int st = X.st[lane];
+        double kk = 0.0, rdiag = 1.0;
+        int fr = 0, ok = 0;
+        bool go = act && rc == BW_OK;
+        if (go) {
+            if (st != BW_OK) { // the helper's PD test: np.all(np.linalg.eigvals(Q_uu) > 0)   (:137-140)
+                rc = st;
+                stopped_at = st == BW_NOT_PD ? i : stopped_at;
+                go = false;
+            } else {
+                bool fg;
+                boxqp1_guess(QO, qp_tab, Quu, rL, Qu, bd.lo - u, bd.hi - u, k0, kk, fg);
+                rdiag = rL;
+                fr = fg ? 1 : 0;
+                ok = 1;
+            }
+        }
+        X.kk[lane] = kk;
+        X.rdiag[lane] = rdiag;
+        X.free_[lane] = fr;
+        X.ok[lane] = ok;
+        PP_T(t2);
+        PP_ADD(0, 1, t1, t2);
+        pair_barrier(); // #2: the helper goes on with K and the value update, on the guess
+        __builtin_amdgcn_sched_barrier(0); // (the verification below must not be scheduled in front of the hand-over)
+        PP_T(t3);
+        PP_ADD(0, 2, t2, t3);
+        bool wrong = false;
+        if (go) {
+            QP1Out qp;
+            boxqp1(QO, qp_tab, Quu, L, rL, Qu, bd.lo - u, bd.hi - u, k0, qp); // :152-156
+            // (the factor only enters K, and K is zero for a clamped control)
+            wrong = !(qp.x == kk) | ((qp.free_ ? 1 : 0) != fr) | (qp.free_ & !(qp.rdiag == rdiag));
+            kk = qp.x;
+            rdiag = qp.rdiag;
+            fr = qp.free_ ? 1 : 0;
+            S.qp_iter += qp.n_iter;
+            S.qp_backtrack += qp.n_backtrack;
+            S.n_clamped += qp.free_ ? 0 : 1;
+            // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)                 (:175-176)
+            S.dJ1 = S.dJ1 + kk * Qu;
+            S.dJ2 = S.dJ2 + (kk * (Quu * kk)) * 0.5;
+        }
+        if (__ballot(wrong) != 0ull) { // the verified outcome of every lane, and the flag that makes the helper use it
+            PP_COUNT(0, 4);
+            X.kk2[lane] = kk;
+            X.rdiag2[lane] = rdiag;
+            X.free2[lane] = fr;
+            if (lane == 0)
+                X.fix = 1;
+            fix = true;
+        }
+        if (act)
+            k[(int64_t)i * ld + b] = kk;
+        u = up;
+        PP_T(t4);
+        PP_ADD(0, 3, t3, t4);
+    }
+    pair_barrier(); // the verdict on the guess of step 0 is in X
+    PP_FLUSH(0);
+    return rc;
+}
+
+// Helper half of the same sweep.  K [T*5, ld] is written for the lanes that take part.
+template <class Cost>
+__device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost& C, int T, int64_t ld, int64_t b,
+                                                  PairX& X, int lane, bool act, const double* __restrict__ xs,
+                                                  const double* __restrict__ us, double mu, double* __restrict__ K)
+{
+    BwAcc S;
+    double xnext[NX];
+    load5(xs, ld, (int64_t)T * NX, b, xnext);
+    C.at_terminal(T);
+    bw_init(C, xnext, S);
+    double x[NX], u, xq[NX], uq; // operands of step i and of step i-1
+    load5(xs, ld, (int64_t)(T - 1) * NX, b, x);
+    u = us[(int64_t)(T - 1) * ld + b];
+    {
+        const int iq = T > 1 ? T - 2 : 0;
+        load5(xs, ld, (int64_t)iq * NX, b, xq);
+        uq = us[(int64_t)iq * ld + b];
+    }
+    CartpoleJac J; // of step i: sin/cos of the next angle are entries 2, 3 of the next state
+    cartpole_jac(P, x, u, xnext[2], xnext[3], J);
+    const double dt = P.dt;
+    bool live = act, live_before = act; // live_before: before the outcome of the step in hand was applied
+    PP_DECL;
+    // Loop-carried across the hand-over: the Q-terms, gains and boxQP outcome of the step before, whose value
+    // update (all but the six numbers the master needed) and K store are completed after barrier #1.
+    bool pending = false;
+    double Qx[NX], Qxx[NX * NX], Qux[NX], Kr[NX], T1[NX], kk = 0.0, Qu = 0.0, Quu = 1.0;
+    // K, T1 = K Q_uu from the boxQP outcome (guessed or verified)   (:157-160)
+    auto gains = [&](double rdiag, bool fr) {
+#pragma unroll
+        for (int bb = 0; bb < NX; ++bb) {
+            Kr[bb] = (live && fr) ? ((Qux[bb] * rdiag) * rdiag) * -1 : 0.0;
+            T1[bb] = Kr[bb] * Quu;
+        }
+    };
+    // What the master's next step waits for: from the six numbers of V that f_u (non-zero in rows 1 and 4) touches,
+    // Q_u = l_u + f_u^T V_x ; reg = V_xx + mu I ; M2 = f_u^T reg ; Q_uu = l_uu + M2 f_u   (:207, :210-212), the PD
+    // test, the Cholesky factor and the (positive-sign) boxQP warm start (:137-145).  lu_n, luu_n, J: of that step.
+    auto publish = [&](double v11, double v14, double v41, double v44, double vx1, double vx4, double lu_n,
+                       double luu_n) {
+        const double b1 = J.b1, b4 = J.b4;
+        const double Qu_n = lu_n + fma(b4, vx4, b1 * vx1);
+        const double M2_1 = fma(b4, v41 + 0.0, b1 * (v11 + mu));
+        const double M2_4 = fma(b4, v44 + mu, b1 * (v14 + 0.0));
+        const double Quu_n = luu_n + fma(M2_4, b4, M2_1 * b1);
+        const int st = !(fabs(Quu_n) < __builtin_inf()) ? BW_LINALG : (!(Quu_n > 0.0) ? BW_NOT_PD : BW_OK);
+        const double L = sqrt(Quu_n);
+        const double rL = 1.0 / L;
+        X.v[0][lane] = Quu_n;
+        X.v[1][lane] = Qu_n;
+        X.v[2][lane] = L;
+        X.v[3][lane] = rL;
+        X.v[4][lane] = (Qu_n * rL) * rL;
+        X.st[lane] = st;
+    };
+    // ... after step i (whose Q-terms, gains and k are in hand), for step i-1 (operands xq, uq; its Jacobian is in J)
+    auto hand_over = [&](int i) {
+        const double vn11 = ((Qxx[1 * NX + 1] + T1[1] * Kr[1]) + Kr[1] * Qux[1]) + Qux[1] * Kr[1];
+        const double vn14 = ((Qxx[1 * NX + 4] + T1[1] * Kr[4]) + Kr[1] * Qux[4]) + Qux[1] * Kr[4];
+        const double vn41 = ((Qxx[4 * NX + 1] + T1[4] * Kr[1]) + Kr[4] * Qux[1]) + Qux[4] * Kr[1];
+        const double vn44 = ((Qxx[4 * NX + 4] + T1[4] * Kr[4]) + Kr[4] * Qux[4]) + Qux[4] * Kr[4];
+        const double v14 = 0.5 * (vn14 + vn41);
+        const double vx1 = ((Qx[1] + T1[1] * kk) + Kr[1] * Qu) + Qux[1] * kk;
+        const double vx4 = ((Qx[4] + T1[4] * kk) + Kr[4] * Qu) + Qux[4] * kk;
+        C.at(i > 0 ? i - 1 : 0);
+        publish(0.5 * (vn11 + vn11), v14, v14, 0.5 * (vn44 + vn44), vx1, vx4, C.lu(uq), C.luu());
+    };
+    C.at(T - 1);
+    publish(S.Vxx[1 * NX + 1], S.Vxx[1 * NX + 4], S.Vxx[4 * NX + 1], S.Vxx[4 * NX + 4], S.Vx[1], S.Vx[4], C.lu(u), C.luu());
+    for (int i = T - 1; i >= 0; --i) {
+        PP_T(t0);
+        pair_barrier(); // #1: the master has verified its guess of step i+1
+        if (X.fix != 0) { // wrong in some lane: the six numbers again, from the verified outcome of every lane
+            kk = X.kk2[lane];
+            live = live_before && (X.ok[lane] != 0);
+            gains(X.rdiag2[lane], X.free2[lane] != 0);
+            hand_over(i + 1);
+            pair_barrier(); // #1b
+        }
+        PP_T(t1);
+        PP_ADD(1, 0, t0, t1);
+        if (pending) { // step i+1: its K, and every entry of its value update
+            // (arithmetic on registers may be scheduled across a barrier; what follows must not drift back
+            // in front of the hand-over, where the master would wait for it: pin its inputs here)
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                asm volatile("" : "+v"(Kr[a]));
+                asm volatile("" : "+v"(T1[a]));
+            }
+            asm volatile("" : "+v"(kk));
+            if (act)
+                store5(K, ld, (int64_t)(i + 1) * NX, b, Kr);
+            // V_x = Q_x + K^T Q_uu k + K^T Q_u + Q_ux^T k ; V_xx = Q_xx + K^T Q_uu K + K^T Q_ux + Q_ux^T K,
+            // symmetrised   (:164-169)
+            double Vn[NX * NX];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                S.Vx[a] = ((Qx[a] + T1[a] * kk) + Kr[a] * Qu) + Qux[a] * kk;
+#pragma unroll
+                for (int bb = 0; bb < NX; ++bb)
+                    Vn[a * NX + bb] = ((Qxx[a * NX + bb] + T1[a] * Kr[bb]) + Kr[a] * Qux[bb]) + Qux[a] * Kr[bb];
+            }
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+#pragma unroll
+                for (int bb = a; bb < NX; ++bb) {
+                    double v = 0.5 * (Vn[a * NX + bb] + Vn[bb * NX + a]);
+                    S.Vxx[a * NX + bb] = v;
+                    S.Vxx[bb * NX + a] = v;
+                }
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+                x[a] = xq[a];
+            u = uq;
+        }
+        {   // operands of step i-1 (for its Jacobian, formed at the end of this step's Q-terms)
+            const int iq = i > 0 ? i - 1 : 0;
+            load5(xs, ld, (int64_t)iq * NX, b, xq);
+            uq = us[(int64_t)iq * ld + b];
+        }
+        // ---- the part of _compute_Q_terms (:179-228) that does not wait for the boxQP
+        C.at(i);
+        double lx[NX];
+        C.lx(x, lx);
+        const double lu = C.lu(u);
+        const double(&A)[4][3] = J.a;
+        const double* Vx = S.Vx;
+        const double* Vxx = S.Vxx;
+        Qx[0] = lx[0] + Vx[0];
+        Qx[1] = lx[1] + (dt * Vx[0] + Vx[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = A[0][c] * Vx[1];
+            acc = fma(A[1][c], Vx[2], acc);
+            acc = fma(A[2][c], Vx[3], acc);
+            acc = fma(A[3][c], Vx[4], acc);
+            Qx[2 + c] = lx[2 + c] + acc;
+        }
+        Qu = lu + fma(J.b4, Vx[4], J.b1 * Vx[1]);
+        double M1[NX * NX];
+#pragma unroll
+        for (int bb = 0; bb < NX; ++bb) {
+            M1[0 * NX + bb] = Vxx[0 * NX + bb];
+            M1[1 * NX + bb] = dt * Vxx[0 * NX + bb] + Vxx[1 * NX + bb];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double acc = A[0][c] * Vxx[1 * NX + bb];
+                acc = fma(A[1][c], Vxx[2 * NX + bb], acc);
+                acc = fma(A[2][c], Vxx[3 * NX + bb], acc);
+                acc = fma(A[3][c], Vxx[4 * NX + bb], acc);
+                M1[(2 + c) * NX + bb] = acc;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            Qxx[a * NX + 0] = C.add_lxx(a, 0, M1[a * NX + 0]);
+            Qxx[a * NX + 1] = C.add_lxx(a, 1, M1[a * NX + 0] * dt + M1[a * NX + 1]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double acc = M1[a * NX + 1] * A[0][c];
+                acc = fma(M1[a * NX + 2], A[1][c], acc);
+                acc = fma(M1[a * NX + 3], A[2][c], acc);
+                acc = fma(M1[a * NX + 4], A[3][c], acc);
+                Qxx[a * NX + 2 + c] = C.add_lxx(a, 2 + c, acc);
+            }
+        }
+        double M2[NX];
+#pragma unroll
+        for (int bb = 0; bb < NX; ++bb) {
+            double r1 = Vxx[1 * NX + bb] + (bb == 1 ? mu : 0.0);
+            double r4 = Vxx[4 * NX + bb] + (bb == 4 ? mu : 0.0);
+            M2[bb] = fma(J.b4, r4, J.b1 * r1);
+        }
+        Qux[0] = 0.0 + M2[0];
+        Qux[1] = 0.0 + (M2[0] * dt + M2[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = M2[1] * A[0][c];
+            acc = fma(M2[2], A[1][c], acc);
+            acc = fma(M2[3], A[2][c], acc);
+            acc = fma(M2[4], A[3][c], acc);
+            Qux[2 + c] = 0.0 + acc;
+        }
+        Quu = C.luu() + fma(M2[4], J.b4, M2[1] * J.b1);
+        // ---- the Jacobian of step i-1 (operands xq, uq; its next state is x), while the master is still in its boxQP
+        cartpole_jac(P, xq, uq, x[2], x[3], J);
+        // (pure arithmetic may be scheduled across a barrier: everything the hand-over after #2 reads must be
+        // in registers before the wait, not computed behind it, where the master would wait for it)
+        asm volatile("" : "+v"(Qxx[1 * NX + 1]), "+v"(Qxx[1 * NX + 4]), "+v"(Qxx[4 * NX + 1]), "+v"(Qxx[4 * NX + 4]));
+        asm volatile("" : "+v"(Qx[1]), "+v"(Qx[4]), "+v"(Qu), "+v"(Quu), "+v"(J.b1), "+v"(J.b4));
+        asm volatile("" : "+v"(Qux[0]), "+v"(Qux[1]), "+v"(Qux[2]), "+v"(Qux[3]), "+v"(Qux[4]));
+        PP_T(t2);
+        PP_ADD(1, 1, t1, t2);
+        pair_barrier(); // #2: the master's guess of k, factor and free mask of step i is in X
+        PP_T(t3);
+        PP_ADD(1, 2, t2, t3);
+        kk = X.kk[lane];
+        live_before = live;
+        live = live && (X.ok[lane] != 0);
+        gains(X.rdiag[lane], X.free_[lane] != 0);
+        hand_over(i);
+        pending = true;
+        PP_T(t4);
+        PP_ADD(1, 3, t3, t4);
+    }
+    pair_barrier(); // the master's verdict on its guess of step 0
+    if (X.fix != 0) {
+        live = live_before && (X.ok[lane] != 0);
+        gains(X.rdiag2[lane], X.free2[lane] != 0);
+    }
+    if (act) // step 0
+        store5(K, ld, 0, b, Kr);
+    PP_FLUSH(1);
+}
+
 // ------------------------------------------------------------- whole solve
 
 // Diagnostic: when set (ilqr_debug_wave_log), every wave of k_solve records its start
@@ -661,7 +1038,12 @@ constexpr int LS_MAXA = 32;  // largest alpha schedule
 // Compiled for one wave per SIMD (up to 512 registers, no spills): a build for two
 // waves per SIMD spills ~400 bytes per lane and is slower at every batch size measured
 // (158 vs 114 ms at 65536 problems, 227 vs 214 ms at 131072).
-template <class Cost>
+//
+// PAIR: the launch consists of 128-thread workgroups, wavefront 0 of each the master that runs everything
+// below, wavefront 1 its helper in the backward sweeps (see pair_master_sweep).
+struct NoPair {
+};
+template <class Cost, bool PAIR>
 __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, SolveOptsP O, BoundsP bd, int T,
                                                 int64_t B, SolveBuffers W,
                                                 double* __restrict__ delta_io,
@@ -673,16 +1055,22 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     __shared__ double s_J[4][LS_PASS][LS_MAXA];
     __shared__ int s_lane[4][LS_PASS], s_cur[4][LS_PASS], s_gcur[4][LS_PASS];
     __shared__ double s_qp_tab[QP_TAB];
+    __shared__ typename std::conditional<PAIR, PairX, NoPair>::type s_pair;
 
     // problems per wavefront (64, 32 or 16): a small batch is spread thinly over all SIMDs, which costs a
     // wave nothing (an instruction takes as long for 16 lanes as for 64) and makes the wave-level slow
     // paths (boxQP fallbacks, the cooperative line search) rarer per wave
     const int lane = threadIdx.x & 63;
     const int lpw = O.lanes_per_wave;
-    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // PAIR: one group of problems per workgroup.  Groups 2j and 2j+1 share a 64-column workspace tile when
+    // lpw = 32; consecutive workgroups go to different XCDs, so the tile-mates are workgroups 16c + r and
+    // 16c + r + 8 (the same XCD under round-robin placement) rather than neighbours.
+    const int64_t wave_global =
+        PAIR ? ((int64_t)(blockIdx.x >> 4) << 4) + ((blockIdx.x & 7) << 1) + ((blockIdx.x >> 3) & 1)
+             : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t gb = wave_global * lpw + lane; // problem index
     const bool valid = lane < lpw && gb < B;
-    const int wv = threadIdx.x >> 6; // wave within the workgroup (each wave only talks to itself)
+    const int wv = PAIR ? 0 : threadIdx.x >> 6; // wave within the workgroup (each wave only talks to itself)
     if (threadIdx.x < LS_MAXA)
         s_alpha[threadIdx.x] = O.alphas[threadIdx.x];
     qp_fill_step_table(s_qp_tab, O.qp.step_dec); // ends with the workgroup barrier
@@ -718,6 +1106,20 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     CartpoleC P = cartpole_consts(mp);
     Cost C(Cp);
     QPOptsP QO = qp_opts_in_vgprs(O.qp);
+    if constexpr (PAIR) {
+        if ((threadIdx.x >> 6) == 1) { // the helper: one backward sweep per command of the master
+            for (;;) {
+                __syncthreads(); // the master's command, and its stores to the trajectory (global memory)
+                if (s_pair.cmd == 0)
+                    break;
+                const bool act = s_pair.act[lane] != 0;
+                const int pc = s_pair.cur[lane], pg = s_pair.gnew[lane];
+                pair_helper_sweep(P, C, T, ld, b, s_pair, lane, act, XS(pc), US(pc), s_pair.mu[lane], KG(pg));
+                __syncthreads(); // K is stored: the master's rollouts may read it
+            }
+            return;
+        }
+    }
     int cur = 0;  // trajectory copy in use
     int gcur = 0; // gain copy in use (holds the solver's k_/K_ on entry)
     double mu = 1.0, delta = 2.0, J = 0.0;
@@ -763,11 +1165,46 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         double Jnew = 0.0;
         const int nxt = cur ^ 1;
         bool need = false; // the serial loop would go on to alpha_1
+        if constexpr (PAIR) {
+            // ---- backward pass shared with the helper wavefront; the LinAlgError retry loop (:287-299) as a
+            // wave-uniform loop over the lanes that still want a sweep
+            bool want = running;
+            while (__ballot(want) != 0ull) {
+                const int gnew = gcur ^ 1;
+                s_pair.act[lane] = want ? 1 : 0;
+                s_pair.mu[lane] = mu;
+                s_pair.cur[lane] = cur;
+                s_pair.gnew[lane] = gnew;
+                if (lane == 0)
+                    s_pair.cmd = 1;
+                __syncthreads();
+                BwAcc Sn;
+                int sa;
+                int rc = pair_master_sweep(C, QO, s_qp_tab, bd, T, ld, b, s_pair, lane, want, US(cur), mu, KF(gnew),
+                                           Sn, sa);
+                __syncthreads(); // the helper's K is stored
+                if (want) {
+                    S = Sn;
+                    stopped_at = sa;
+                    if (rc != BW_LINALG) {
+                        gcur = gnew;
+                        dJ1 = Sn.dJ1;
+                        dJ2 = Sn.dJ2;
+                        want = false;
+                    } else {
+                        delta = fmax(delta, 1.0) * O.delta0;
+                        mu = fmax(O.mu_min, mu * delta);
+                        if (O.mu_max != 0.0 && mu >= O.mu_max)
+                            want = false;
+                    }
+                }
+            }
+        }
         if (running) {
             const double* xs = XS(cur);
             const double* us = US(cur);
             // ---- backward pass, with the LinAlgError retry loop (:287-299)
-            bool done = false;
+            bool done = PAIR;
             while (!done) {
                 int gnew = gcur ^ 1;
                 int rc = backward_sweep<true, false>(P, C, QO, s_qp_tab, bd, T, ld, b, xs, us, mu, KF(gnew), KG(gnew),
@@ -903,6 +1340,11 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     }
     if (wave_log != nullptr && lane == 0 && valid)
         wave_log[wave_global * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (PAIR) { // release the helper
+        if (lane == 0)
+            s_pair.cmd = 0;
+        __syncthreads();
+    }
 #undef XS
 #undef US
 #undef KF
@@ -1480,11 +1922,26 @@ static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts,
         if (v == 256 || v == 128 || (v == WAVE && lpw == WAVE))
             blk = v;
     }
+    // Two wavefronts per group of problems (see pair_master_sweep) while that still gives every wavefront a
+    // SIMD of its own: long solves of up to 512 groups.  ILQR_SOLVE_PAIR=0/1 overrides the choice.
+    bool pair = !short_launch && nwaves <= 512;
+    if (const char* e = std::getenv("ILQR_SOLVE_PAIR"))
+        pair = e[0] == '1';
     dim3 grid((unsigned)((nwaves * WAVE + blk - 1) / blk));
+    if (pair) {
+        blk = 2 * WAVE;
+        grid = dim3((unsigned)((nwaves + 15) / 16 * 16)); // whole chunks of 16 groups (the kernel's group <-> workgroup map)
+    }
     int ev = cost_eval(C);
-#define ILQR_LAUNCH_SOLVE(COST)                                                                               \
-    hipLaunchKernelGGL((k_solve<COST>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, iters, \
-                       status, tr)
+#define ILQR_LAUNCH_SOLVE(COST)                                                                                  \
+    do {                                                                                                         \
+        if (pair)                                                                                                \
+            hipLaunchKernelGGL((k_solve<COST, true>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, \
+                               iters, status, tr);                                                               \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_solve<COST, false>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J,    \
+                               mu, iters, status, tr);                                                           \
+    } while (0)
     if (ev == EVAL_DIAG)
         ILQR_LAUNCH_SOLVE(DiagQR);
     else if (ev == EVAL_DENSE)
@@ -1793,6 +2250,16 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
                            B, (int)m, H, g, lower, upper, x0, x, result, Hff, hff_dim, free_mask, counters);
     return hip_status(hipGetLastError());
 }
+
+#ifdef ILQR_PAIR_PROF
+int ilqr_debug_pair_prof(unsigned long long* host16, int reset)
+{
+    unsigned long long z[16] = {0};
+    if (reset)
+        return hip_status(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_prof), z, sizeof(z)));
+    return hip_status(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_pair_prof), sizeof(z)));
+}
+#endif
 
 #ifdef ILQR_QP_PROF
 int ilqr_debug_qp_wave(unsigned int* host2x8192, int reset)

@@ -602,26 +602,34 @@ def test_c_level_chunked_solve_equals_single_launch(hip, B, chunk):
 
 
 def test_every_launch_shape_gives_the_same_bits(hip):
-    """Problems per wavefront and wavefronts per workgroup only change the lane -> problem map."""
+    """Problems per wavefront, wavefronts per workgroup, and one or two wavefronts per group of problems (the
+    backward sweep shared between a master and a helper wavefront) only change which lane computes what."""
     import os
     Mo = co.cartpole_model(T=40)
     M = hip_model(hip, Mo)
     B = 333  # ragged: the last wavefront and the last workspace tile are partly empty in every shape
     x0, us0 = co.cartpole_batch(B, T=Mo.T, seed_x=91, seed_u=92)
-    ref = co.solve(Mo, co.Opts(max_iter=40), x0, us0, nthreads=8, trace=False)
-    saved = {k: os.environ.get(k) for k in ("ILQR_SOLVE_LPW", "ILQR_SOLVE_BLOCK")}
+    ref = co.solve(Mo, co.Opts(max_iter=40), x0, us0, nthreads=8)
+    names = ("ILQR_SOLVE_LPW", "ILQR_SOLVE_BLOCK", "ILQR_SOLVE_PAIR")
+    saved = {k: os.environ.get(k) for k in names}
     try:
-        for lpw, blk in ((None, None), (64, 64), (64, 128), (64, 256), (32, 128), (32, 256), (16, 256)):
-            for key, val in (("ILQR_SOLVE_LPW", lpw), ("ILQR_SOLVE_BLOCK", blk)):
+        for shape in ((None, None, None), (64, 64, 0), (64, 128, 0), (64, 256, 0), (32, 128, 0), (32, 256, 0),
+                      (16, 256, 0), (64, None, 1), (32, None, 1), (16, None, 1)):
+            for key, val in zip(names, shape):
                 if val is None:
                     os.environ.pop(key, None)
                 else:
                     os.environ[key] = str(val)
-            out = hip.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0))
+            out = hip.solve(M, hip.Opts(max_iter=40), dev(x0), dev(us0), trace=True)
             for key in ("xs", "us", "J", "k", "K", "mu", "delta"):
-                assert eq(out[key].cpu().numpy(), ref[key]), (lpw, blk, key)
-            assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"]), (lpw, blk)
-            assert np.array_equal(out["status"].cpu().numpy(), ref["status"]), (lpw, blk)
+                assert eq(out[key].cpu().numpy(), ref[key]), (shape, key)
+            assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"]), shape
+            assert np.array_equal(out["status"].cpu().numpy(), ref["status"]), shape
+            for key in ("J", "accepted", "alpha_idx", "mu", "delta", "qp_iter", "qp_backtrack", "n_clamped", "stopped_at"):
+                tr = out["trace"][key].cpu().numpy().T
+                for b in range(0, B, 7):
+                    it = int(ref["iters"][b])
+                    assert eq(tr[b, :it], ref["trace"][key][b, :it]), (shape, key, b)
     finally:
         for key, val in saved.items():
             if val is None:
