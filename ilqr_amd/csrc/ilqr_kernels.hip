@@ -902,6 +902,20 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
             for (int a = 0; a < NX; ++a)
                 x[a] = xq[a];
             u = uq;
+            // (the update itself is wanted BEFORE the next hand-over, in the time the master spends on its guess:
+            // pin its results here; the Q-terms below may be scheduled on either side)
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                asm volatile("" : "+v"(S.Vx[a]));
+#pragma unroll
+                for (int bb = a; bb < NX; ++bb)
+                    asm volatile("" : "+v"(S.Vxx[a * NX + bb]));
+            }
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+#pragma unroll
+                for (int bb = 0; bb < a; ++bb)
+                    S.Vxx[a * NX + bb] = S.Vxx[bb * NX + a];
         }
         {   // operands of step i-1 (for its Jacobian, formed at the end of this step's Q-terms)
             const int iq = i > 0 ? i - 1 : 0;
@@ -974,11 +988,6 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
         Quu = C.luu() + fma(M2[4], J.b4, M2[1] * J.b1);
         // ---- the Jacobian of step i-1 (operands xq, uq; its next state is x), while the master is still in its boxQP
         cartpole_jac(P, xq, uq, x[2], x[3], J);
-        // (pure arithmetic may be scheduled across a barrier: everything the hand-over after #2 reads must be
-        // in registers before the wait, not computed behind it, where the master would wait for it)
-        asm volatile("" : "+v"(Qxx[1 * NX + 1]), "+v"(Qxx[1 * NX + 4]), "+v"(Qxx[4 * NX + 1]), "+v"(Qxx[4 * NX + 4]));
-        asm volatile("" : "+v"(Qx[1]), "+v"(Qx[4]), "+v"(Qu), "+v"(Quu), "+v"(J.b1), "+v"(J.b4));
-        asm volatile("" : "+v"(Qux[0]), "+v"(Qux[1]), "+v"(Qux[2]), "+v"(Qux[3]), "+v"(Qux[4]));
         PP_T(t2);
         PP_ADD(1, 1, t1, t2);
         pair_barrier(); // #2: the master's guess of k, factor and free mask of step i is in X
@@ -1908,6 +1917,14 @@ static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts,
     // full wave per workgroup and keep that shape.
     const bool short_launch = (int64_t)T * O.max_iter < 2048;
     int lpw = (B <= 32 * 1024 && !short_launch) ? 32 : WAVE;
+    // Long solves of up to 32768 problems run two wavefronts per group of problems (see pair_master_sweep): 32
+    // problems per group up to 16384 problems, 64 above, so that the 2 x 512 wavefronts still have a SIMD each.
+    // ILQR_SOLVE_PAIR=0/1 overrides the choice.
+    bool pair = !short_launch && B <= 32 * 1024;
+    if (const char* e = std::getenv("ILQR_SOLVE_PAIR"))
+        pair = e[0] == '1';
+    if (pair && B > 16 * 1024)
+        lpw = WAVE;
     if (const char* e = std::getenv("ILQR_SOLVE_LPW")) {
         int v = std::atoi(e);
         lpw = (v == 16 || v == 32) ? v : WAVE;
@@ -1922,11 +1939,6 @@ static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts,
         if (v == 256 || v == 128 || (v == WAVE && lpw == WAVE))
             blk = v;
     }
-    // Two wavefronts per group of problems (see pair_master_sweep) while that still gives every wavefront a
-    // SIMD of its own: long solves of up to 512 groups.  ILQR_SOLVE_PAIR=0/1 overrides the choice.
-    bool pair = !short_launch && nwaves <= 512;
-    if (const char* e = std::getenv("ILQR_SOLVE_PAIR"))
-        pair = e[0] == '1';
     dim3 grid((unsigned)((nwaves * WAVE + blk - 1) / blk));
     if (pair) {
         blk = 2 * WAVE;

@@ -674,3 +674,60 @@ def test_backward_pass_giving_up_at_mu_max_reuses_the_previous_sums_across_launc
         ch = hip.solve_chunked(M, hip.Opts(max_iter=8, **kw), dev(x0), dev(us0), chunk, delta=dev(d0))
         for key in ("xs", "us", "J", "k", "K", "mu", "delta", "iters", "status"):
             assert torch.equal(one[key], ch[key]), (chunk, key)
+
+
+@pytest.mark.parametrize("pair", ["1", "0"])
+def test_two_wavefront_sweep_on_the_rare_paths(hip, monkeypatch, pair):
+    """The backward sweep shared by two wavefronts (long solves of up to 32768 problems take it by default;
+    forced here on short ones) through the paths a swing-up batch rarely visits: the LinAlgError retry loop
+    that gives up at mu_max, non-PD breaks (ilqr_core.py:137-140), wrong guesses of the boxQP outcome (the
+    warm-started re-solves of a closed loop end their boxQP on other paths than a cold solve), and lanes
+    that leave the loop at different iterations."""
+    monkeypatch.setenv("ILQR_SOLVE_PAIR", pair)  # ("0": the same paths through the one-wavefront sweep)
+    # (a) giving up at mu_max, with non-PD breaks on the way (see the test of that name above)
+    B, T = 70, 6
+    Mo = co.cartpole_model(T=T, dt=1.5)
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=5, seed_u=6)
+    x0[:, [0, 1, 4]] *= 0.1
+    us0 *= 0.1
+    kw = dict(scale=1e30, mu_max=1.5e308)
+    d0 = np.full(B, 1e102)
+    ref = co.solve(Mo, co.Opts(max_iter=8, **kw), x0, us0, delta=d0, nthreads=8)
+    assert (ref["trace"]["stopped_at"] >= 0).any()
+    out = hip.solve(hip_model(hip, Mo), hip.Opts(max_iter=8, **kw), dev(x0), dev(us0), delta=dev(d0), trace=True)
+
+    def same(out, ref, B, counters_upto=None):
+        assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        for key in ("J", "xs", "us", "k", "K", "mu", "delta"):
+            assert eq(out[key].cpu().numpy(), ref[key]), key
+        for key in ("alpha_idx", "accepted", "J", "mu", "delta", "stopped_at", "qp_iter", "qp_backtrack", "n_clamped"):
+            tr = out["trace"][key].cpu().numpy().T
+            for b in range(B):
+                it = int(ref["iters"][b])
+                if counters_upto is not None and key in ("qp_iter", "qp_backtrack", "n_clamped"):
+                    it = min(it, counters_upto)
+                assert eq(tr[b, :it], ref["trace"][key][b, :it]), (key, b)
+    # The boxQP counters of the abandoned sweep (iteration 3) are left out: with mu = 6.4e307 entries of V_xx + mu I
+    # overflow to inf in two of the problems, where the reference's dense products turn 0 * inf into NaN one step
+    # earlier than a sweep that skips the structural zeros of f_u; the sweep is abandoned either way and nothing
+    # of it is used.
+    same(out, ref, B, counters_upto=3)
+    # (b) the closed-loop configuration (N = 15, force limit 20, pole length 0.5): a cold solve, then a
+    # warm-started re-solve from the shifted controls with the carried delta, k, K
+    B, T = 300, 15
+    Mo = co.cartpole_model(T=T, max_control=20.0, l=0.5, mpc=True)
+    M = hip_model(hip, Mo)
+    r = np.random.RandomState(77)
+    st = np.stack([r.uniform(-0.05, 0.05, B), r.uniform(-0.05, 0.05, B), np.pi / 2 + r.uniform(-0.05, 0.05, B),
+                   r.uniform(-0.05, 0.05, B)], axis=1)
+    x0, us0 = co.augment_state(st), r.uniform(-1, 1, (B, T, 1))
+    ref = co.solve(Mo, co.Opts(max_iter=200), x0, us0, nthreads=8)
+    out = hip.solve(M, hip.Opts(max_iter=200), dev(x0), dev(us0), trace=True)
+    same(out, ref, B)
+    us1 = np.concatenate([ref["us"][:, 1:], ref["us"][:, -1:]], axis=1)
+    ref2 = co.solve(Mo, co.Opts(max_iter=10), ref["xs"][:, 1], us1, delta=ref["delta"], k=ref["k"], K=ref["K"], nthreads=8)
+    out2 = hip.solve(M, hip.Opts(max_iter=10), dev(ref["xs"][:, 1]), dev(us1), delta=dev(ref["delta"]), k=dev(ref["k"]),
+                     K=dev(ref["K"]), trace=True)
+    same(out2, ref2, B)
+    assert len(np.unique(ref["iters"])) > 3
