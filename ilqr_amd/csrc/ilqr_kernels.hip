@@ -1112,6 +1112,9 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
 #define KG(i) ((i) ? K1 : K0)
     const int64_t ld = 64;
     const int64_t b = gb & 63; // column of the problem in its tile
+    // lanes without a problem take part in the two-wavefront sweeps with a column of their own group, so that
+    // their (discarded) loads touch no memory the group does not read anyway
+    const int64_t bq = valid ? b : ((wave_global * lpw) & 63);
     CartpoleC P = cartpole_consts(mp);
     Cost C(Cp);
     QPOptsP QO = qp_opts_in_vgprs(O.qp);
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                     break;
                 const bool act = s_pair.act[lane] != 0;
                 const int pc = s_pair.cur[lane], pg = s_pair.gnew[lane];
-                pair_helper_sweep(P, C, T, ld, b, s_pair, lane, act, XS(pc), US(pc), s_pair.mu[lane], KG(pg));
+                pair_helper_sweep(P, C, T, ld, bq, s_pair, lane, act, XS(pc), US(pc), s_pair.mu[lane], KG(pg));
                 __syncthreads(); // K is stored: the master's rollouts may read it
             }
             return;
@@ -1189,7 +1192,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                 __syncthreads();
                 BwAcc Sn;
                 int sa;
-                int rc = pair_master_sweep(C, QO, s_qp_tab, bd, T, ld, b, s_pair, lane, want, US(cur), mu, KF(gnew),
+                int rc = pair_master_sweep(C, QO, s_qp_tab, bd, T, ld, bq, s_pair, lane, want, US(cur), mu, KF(gnew),
                                            Sn, sa);
                 __syncthreads(); // the helper's K is stored
                 if (want) {
