@@ -280,7 +280,9 @@ def cartpole_roofline(B, iters, kernel_ms, chunked):
     prob_iters = int(iters.sum())
     dur_s = kernel_ms * 1e-3
     cnt = load_counters("cartpole", B)
-    sector = sector_granular_factor(iters)
+    # the chunked solve drops finished problems between launches, so a sector's 8 problems leave together
+    # with at most one chunk's delay: the whole-solve factor does not apply to it
+    sector = 1.0 if chunked else sector_granular_factor(iters)
     fused_bytes = prob_iters * (FUSED_READ_BYTES + FUSED_WRITE_BYTES)
     flops = prob_iters * (FLOP_BACKWARD + FLOP_ROLLOUT)
     staged = {"algorithmic_bytes_per_launch": prob_iters * STAGED_BYTES_PER_PROBLEM_ITER,
@@ -292,7 +294,7 @@ def cartpole_roofline(B, iters, kernel_ms, chunked):
                       "design, not a utilisation" % STAGED_BYTES_PER_PROBLEM_ITER}
     fused = {"bytes_per_problem_iteration": FUSED_READ_BYTES + FUSED_WRITE_BYTES,
              "bytes_per_launch": fused_bytes,
-             "sector_granularity_factor": sector,
+             "sector_granularity_factor": None if chunked else sector,
              "expected_hbm_bytes_per_launch": fused_bytes * sector,
              "note": "xs, us in / k, K out (backward sweep) + xs, us, k, K in / xs, us out (accepted rollout); "
                      "memory moves 64-byte sectors = 8 neighbouring problems, alive until the slowest of the 8 "
@@ -304,7 +306,7 @@ def cartpole_roofline(B, iters, kernel_ms, chunked):
               "conversions inside the timed span)")
     hbm_bound = B >= 65536  # one 64-problem wavefront on every SIMD: the ping-pong workspace streams through HBM
     if hbm_bound:
-        moved = traffic if traffic else fused_bytes * (1.0 if chunked else sector)
+        moved = traffic if traffic else fused_bytes * sector
         roof = {"bound": "hbm", "achieved": moved / dur_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": moved / dur_s / 1e9 / HBM_PEAK_GBS,
                 "basis": "PMC-measured bytes" if traffic else "fused-design bytes of this run's iteration counts"}
