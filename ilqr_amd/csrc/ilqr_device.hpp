@@ -780,11 +780,18 @@ __device__ __forceinline__ bool qp_exhausts(const QPOptsP& O, double H, double g
     return (xc1 == x) | qp_spin_proved(O, H, G, gerr, descent, D0, Ep);
 }
 
+// mid(): called exactly once, between pass 0 and pass 1 (a caller that shares the work with other wavefronts
+// meets them there; see pair_verifier_sweep).
+struct QPNoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <class Mid = QPNoMid>
 __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, double H, double sqrtH, double rsqrtH,
-                                       double g, double lo, double hi, double x0, QP1Out& out)
+                                       double g, double lo, double hi, double x0, QP1Out& out, Mid mid = Mid())
 {
     const bool opts_ok = (O.max_iter >= 3) & (O.armijo > 0.0) & (O.armijo < 1.0); // wave-uniform
     if (!opts_ok) {
+        mid();
         boxqp1_loop(O, tab, H, sqrtH, rsqrtH, g, lo, hi, x0, out);
         return;
     }
@@ -826,6 +833,9 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
         double hv = (0.5 * H * uv) * uv - ((1.0 - O.armijo) * (G + gerr)) * uv - O.armijo * 1e-10;
         jump = try_jump & (hv > Ep) & (fabs(dv * grad0) > 1.0000001e-10) & !s;
     }
+#ifdef ILQR_QP_MID_EARLY
+    mid();
+#endif
     int n0 = jump ? tj : 0;
     double xb, vb;
     s = false;
@@ -844,6 +854,9 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
         n0 = exh0 ? O.n_exhaust : n0;
     }
 
+#ifndef ILQR_QP_MID_EARLY
+    mid();
+#endif
     // ---- pass 1: factorised Newton step
     const bool act1 = act0 & !exh0;
     const double grad1 = g + H * xb;

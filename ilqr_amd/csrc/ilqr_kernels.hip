@@ -662,6 +662,9 @@ struct PairX {
     double mu[64];            // per sweep, master -> helper
     int act[64], cur[64], gnew[64];
     int cmd;                  // 1 = run a sweep, 0 = leave
+    double dJ[2][64];         // per sweep, verifier -> master (three wavefronts): Delta_J1, Delta_J2 ...
+    int cnt[3][64];           // ... and the boxQP counters
+    double ja[14][64];        // master -> helper (three wavefronts): the Jacobian of the step after next
 };
 
 // LDS hand-over between the two wavefronts of a pair: waits for LDS only, so global loads issued ahead
@@ -674,7 +677,7 @@ __device__ __forceinline__ void pair_barrier()
 }
 
 #ifdef ILQR_PAIR_PROF // diagnostic build only: shader clocks of the two halves of the shared backward sweep
-static __device__ unsigned long long g_pair_prof[2][8];
+static __device__ unsigned long long g_pair_prof[3][8];
 #define PP_DECL unsigned long long pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PP_T(var) const long long var = __builtin_amdgcn_s_memtime()
 #define PP_ADD(role, slot, a, bq) pp_acc[slot] += (unsigned long long)((bq) - (a))
@@ -694,11 +697,13 @@ static __device__ unsigned long long g_pair_prof[2][8];
 // Master half of one backward sweep.  act: the lane takes part (its problem still needs this backward pass).
 // S receives Delta_J and the boxQP counters; k [T, ld] is written for the lanes that take part (zeros where
 // the sweep did not reach).
-template <class Cost>
+// VERIFY = false: a third wavefront runs the verification (pair_verifier_sweep); the master only guesses.
+template <class Cost, bool VERIFY>
 __device__ __forceinline__ int pair_master_sweep(const Cost& C, const QPOptsP& QO, const double* qp_tab,
                                                  const BoundsP& bd, int T, int64_t ld, int64_t b, PairX& X, int lane,
                                                  bool act, const double* __restrict__ us, double mu,
-                                                 double* __restrict__ k, BwAcc& S, int& stopped_at)
+                                                 double* __restrict__ k, BwAcc& S, int& stopped_at,
+                                                 const CartpoleC& P, const double* __restrict__ xs)
 {
     S.dJ1 = 0.0;
     S.dJ2 = 0.0;
@@ -707,17 +712,33 @@ __device__ __forceinline__ int pair_master_sweep(const Cost& C, const QPOptsP& Q
     int rc = BW_OK;
     double u = us[(int64_t)(T - 1) * ld + b];
     PP_DECL;
+#ifdef ILQR_PAIR_PROF
+    const int O_n_exhaust_dbg = QO.n_exhaust;
+#endif
     if (lane == 0)
         X.fix = 0;
     bool fix = false; // wave-uniform: the guess of the step before was wrong in some lane
+    // three wavefronts: the master, idle while the other two work on its guess, forms the Jacobian of step i-2
+    // for the helper (which reads it after hand-over #1 of step i-1 and has those of steps T-1, T-2 itself)
+    double xm[NX];
+    if (!VERIFY)
+        load5(xs, ld, (int64_t)(T > 1 ? T - 2 : 0) * NX, b, xm);
     for (int i = T - 1; i >= 0; --i) {
         const int ip = i > 0 ? i - 1 : 0;
         const double up = us[(int64_t)ip * ld + b]; // operand of the step before, loaded ahead
+        double xj[NX], uj = 0.0;
+        if (!VERIFY) {
+            const int ij = i > 1 ? i - 2 : 0;
+            load5(xs, ld, (int64_t)ij * NX, b, xj);
+            uj = us[(int64_t)ij * ld + b];
+        }
         PP_T(t0);
         pair_barrier(); // #1: the helper's numbers of step i are in X (formed from the guess of step i+1) ...
+        if (!VERIFY)
+            fix = X.fix != 0; // the verifier's flag (it also clears it)
         if (fix) { // ... which was wrong: the helper is forming them again from the verified outcome
             pair_barrier(); // #1b
-            if (lane == 0)
+            if (VERIFY && lane == 0)
                 X.fix = 0;
             fix = false;
         }
@@ -752,11 +773,22 @@ __device__ __forceinline__ int pair_master_sweep(const Cost& C, const QPOptsP& Q
         PP_T(t3);
         PP_ADD(0, 2, t2, t3);
         bool wrong = false;
-        if (go) {
+        if (VERIFY && go) {
             QP1Out qp;
             boxqp1(QO, qp_tab, Quu, L, rL, Qu, bd.lo - u, bd.hi - u, k0, qp); // :152-156
             // (the factor only enters K, and K is zero for a clamped control)
             wrong = !(qp.x == kk) | ((qp.free_ ? 1 : 0) != fr) | (qp.free_ & !(qp.rdiag == rdiag));
+#ifdef ILQR_PAIR_PROF
+            {
+                const bool exh = qp.n_backtrack >= O_n_exhaust_dbg;
+                const int cls = qp.n_iter == 0 ? 0 : (qp.n_iter == 1 ? 1 : (exh ? 2 : 3));
+                for (int c = 0; c < 4; ++c) {
+                    unsigned long long m = __ballot(wrong && cls == c);
+                    if (m != 0ull && lane == 0 && blockIdx.x == 0)
+                        atomicAdd(&g_pair_prof[1][4 + c], (unsigned long long)__popcll(m));
+                }
+            }
+#endif
             kk = qp.x;
             rdiag = qp.rdiag;
             fr = qp.free_ ? 1 : 0;
@@ -767,8 +799,121 @@ __device__ __forceinline__ int pair_master_sweep(const Cost& C, const QPOptsP& Q
             S.dJ1 = S.dJ1 + kk * Qu;
             S.dJ2 = S.dJ2 + (kk * (Quu * kk)) * 0.5;
         }
-        if (__ballot(wrong) != 0ull) { // the verified outcome of every lane, and the flag that makes the helper use it
-            PP_COUNT(0, 4);
+        if (!VERIFY) {
+            CartpoleJac Jm;
+            cartpole_jac(P, xj, uj, xm[2], xm[3], Jm);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    X.ja[r * 3 + c][lane] = Jm.a[r][c];
+            X.ja[12][lane] = Jm.b1;
+            X.ja[13][lane] = Jm.b4;
+#pragma unroll
+            for (int a = 0; a < NX; ++a)
+                xm[a] = xj[a];
+        }
+        if (VERIFY) {
+            if (__ballot(wrong) != 0ull) { // the verified outcome of every lane, and the flag that makes the helper use it
+                PP_COUNT(0, 4);
+                X.kk2[lane] = kk;
+                X.rdiag2[lane] = rdiag;
+                X.free2[lane] = fr;
+                if (lane == 0)
+                    X.fix = 1;
+                fix = true;
+            }
+            if (act)
+                k[(int64_t)i * ld + b] = kk;
+        }
+        u = up;
+        PP_T(t4);
+        PP_ADD(0, 3, t3, t4);
+    }
+    pair_barrier(); // the verdict on the guess of step 0 is in X
+    if (!VERIFY) { // ... and the verifier's sums
+        S.dJ1 = X.dJ[0][lane];
+        S.dJ2 = X.dJ[1][lane];
+        S.qp_iter = X.cnt[0][lane];
+        S.qp_backtrack = X.cnt[1][lane];
+        S.n_clamped = X.cnt[2][lane];
+    }
+    PP_FLUSH(0);
+    return rc;
+}
+
+// Third wavefront of a group: runs boxqp1 in full on the numbers the helper handed over, compares the outcome
+// with the master's guess, raises the flag that makes the helper redo a step after a wrong guess, stores k and
+// accumulates Delta_J and the boxQP counters (handed to the master at the end of the sweep).  It meets the
+// other two at every hand-over; the hand-over of the guess (#2) falls between the boxQP's first and second pass.
+__device__ __forceinline__ void pair_verifier_sweep(const QPOptsP& QO, const double* qp_tab, const BoundsP& bd, int T,
+                                                    int64_t ld, int64_t b, PairX& X, int lane, bool act,
+                                                    const double* __restrict__ us, double* __restrict__ k)
+{
+    double dJ1 = 0.0, dJ2 = 0.0;
+    int qp_iter = 0, qp_backtrack = 0, n_clamped = 0;
+    bool ended = false; // the lane's sweep has ended (not PD / non-finite Q_uu)
+    double u = us[(int64_t)(T - 1) * ld + b];
+    bool fix = false;
+    PP_DECL;
+    for (int i = T - 1; i >= 0; --i) {
+        const int ip = i > 0 ? i - 1 : 0;
+        const double up = us[(int64_t)ip * ld + b];
+        PP_T(t0);
+        pair_barrier(); // #1
+        if (fix) {
+            pair_barrier(); // #1b
+            if (lane == 0)
+                X.fix = 0;
+            fix = false;
+        }
+        PP_T(t1);
+        PP_ADD(2, 0, t0, t1);
+        const double Quu = X.v[0][lane], Qu = X.v[1][lane], L = X.v[2][lane], rL = X.v[3][lane], k0 = X.v[4][lane];
+        const int st = X.st[lane];
+        ended = ended || st != BW_OK;
+        const bool go = act && !ended;
+        QP1Out qp;
+        long long tmid0 = 0, tmid1 = 0;
+        (void)tmid0;
+        (void)tmid1;
+        // every lane runs the boxQP (the hand-over inside it is the whole wavefront's); lanes without a QP get one
+        // that ends at once, so that no leftover number of theirs sends the wave into a slow path
+        boxqp1(QO, qp_tab, go ? Quu : 1.0, go ? L : 1.0, go ? rL : 1.0, go ? Qu : 0.0, go ? bd.lo - u : -1.0,
+               go ? bd.hi - u : 1.0, go ? k0 : 0.0, qp, [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef ILQR_PAIR_PROF
+            tmid0 = __builtin_amdgcn_s_memtime();
+#endif
+            pair_barrier(); // #2: the master's guess is in X
+#ifdef ILQR_PAIR_PROF
+            tmid1 = __builtin_amdgcn_s_memtime();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef ILQR_PAIR_PROF
+        pp_acc[1] += (unsigned long long)(tmid0 - t1);
+        pp_acc[2] += (unsigned long long)(tmid1 - tmid0);
+#endif
+        double kk = 0.0, rdiag = 1.0;
+        int fr = 0;
+        bool wrong = false;
+        if (go) {
+            const double kg = X.kk[lane], rg = X.rdiag[lane];
+            const int fg = X.free_[lane];
+            // (the factor only enters K, and K is zero for a clamped control)
+            wrong = !(qp.x == kg) | ((qp.free_ ? 1 : 0) != fg) | (qp.free_ & !(qp.rdiag == rg));
+            kk = qp.x;
+            rdiag = qp.rdiag;
+            fr = qp.free_ ? 1 : 0;
+            qp_iter += qp.n_iter;
+            qp_backtrack += qp.n_backtrack;
+            n_clamped += qp.free_ ? 0 : 1;
+            dJ1 = dJ1 + kk * Qu;
+            dJ2 = dJ2 + (kk * (Quu * kk)) * 0.5;
+        }
+        if (__ballot(wrong) != 0ull) {
+            PP_COUNT(2, 4);
             X.kk2[lane] = kk;
             X.rdiag2[lane] = rdiag;
             X.free2[lane] = fr;
@@ -779,16 +924,22 @@ __device__ __forceinline__ int pair_master_sweep(const Cost& C, const QPOptsP& Q
         if (act)
             k[(int64_t)i * ld + b] = kk;
         u = up;
-        PP_T(t4);
-        PP_ADD(0, 3, t3, t4);
+#ifdef ILQR_PAIR_PROF
+        pp_acc[3] += (unsigned long long)(__builtin_amdgcn_s_memtime() - tmid1);
+#endif
     }
-    pair_barrier(); // the verdict on the guess of step 0 is in X
-    PP_FLUSH(0);
-    return rc;
+    X.dJ[0][lane] = dJ1;
+    X.dJ[1][lane] = dJ2;
+    X.cnt[0][lane] = qp_iter;
+    X.cnt[1][lane] = qp_backtrack;
+    X.cnt[2][lane] = n_clamped;
+    pair_barrier(); // the verdict on the guess of step 0, and the sums, are in X
+    PP_FLUSH(2);
 }
 
 // Helper half of the same sweep.  K [T*5, ld] is written for the lanes that take part.
-template <class Cost>
+// JAC_FROM_MASTER (three wavefronts): the Jacobians of steps T-3 ... 0 come from the master through X.ja.
+template <class Cost, bool JAC_FROM_MASTER>
 __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost& C, int T, int64_t ld, int64_t b,
                                                   PairX& X, int lane, bool act, const double* __restrict__ xs,
                                                   const double* __restrict__ us, double mu, double* __restrict__ K)
@@ -808,6 +959,9 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
     }
     CartpoleJac J; // of step i: sin/cos of the next angle are entries 2, 3 of the next state
     cartpole_jac(P, x, u, xnext[2], xnext[3], J);
+    CartpoleJac Jn; // of step i-1
+    if (JAC_FROM_MASTER)
+        cartpole_jac(P, xq, uq, x[2], x[3], Jn);
     const double dt = P.dt;
     bool live = act, live_before = act; // live_before: before the outcome of the step in hand was applied
     PP_DECL;
@@ -827,8 +981,7 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
     // Q_u = l_u + f_u^T V_x ; reg = V_xx + mu I ; M2 = f_u^T reg ; Q_uu = l_uu + M2 f_u   (:207, :210-212), the PD
     // test, the Cholesky factor and the (positive-sign) boxQP warm start (:137-145).  lu_n, luu_n, J: of that step.
     auto publish = [&](double v11, double v14, double v41, double v44, double vx1, double vx4, double lu_n,
-                       double luu_n) {
-        const double b1 = J.b1, b4 = J.b4;
+                       double luu_n, double b1, double b4) {
         const double Qu_n = lu_n + fma(b4, vx4, b1 * vx1);
         const double M2_1 = fma(b4, v41 + 0.0, b1 * (v11 + mu));
         const double M2_4 = fma(b4, v44 + mu, b1 * (v14 + 0.0));
@@ -844,7 +997,7 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
         X.st[lane] = st;
     };
     // ... after step i (whose Q-terms, gains and k are in hand), for step i-1 (operands xq, uq; its Jacobian is in J)
-    auto hand_over = [&](int i) {
+    auto hand_over = [&](int i, double b1, double b4) {
         const double vn11 = ((Qxx[1 * NX + 1] + T1[1] * Kr[1]) + Kr[1] * Qux[1]) + Qux[1] * Kr[1];
         const double vn14 = ((Qxx[1 * NX + 4] + T1[1] * Kr[4]) + Kr[1] * Qux[4]) + Qux[1] * Kr[4];
         const double vn41 = ((Qxx[4 * NX + 1] + T1[4] * Kr[1]) + Kr[4] * Qux[1]) + Qux[4] * Kr[1];
@@ -853,10 +1006,11 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
         const double vx1 = ((Qx[1] + T1[1] * kk) + Kr[1] * Qu) + Qux[1] * kk;
         const double vx4 = ((Qx[4] + T1[4] * kk) + Kr[4] * Qu) + Qux[4] * kk;
         C.at(i > 0 ? i - 1 : 0);
-        publish(0.5 * (vn11 + vn11), v14, v14, 0.5 * (vn44 + vn44), vx1, vx4, C.lu(uq), C.luu());
+        publish(0.5 * (vn11 + vn11), v14, v14, 0.5 * (vn44 + vn44), vx1, vx4, C.lu(uq), C.luu(), b1, b4);
     };
     C.at(T - 1);
-    publish(S.Vxx[1 * NX + 1], S.Vxx[1 * NX + 4], S.Vxx[4 * NX + 1], S.Vxx[4 * NX + 4], S.Vx[1], S.Vx[4], C.lu(u), C.luu());
+    publish(S.Vxx[1 * NX + 1], S.Vxx[1 * NX + 4], S.Vxx[4 * NX + 1], S.Vxx[4 * NX + 4], S.Vx[1], S.Vx[4], C.lu(u), C.luu(),
+            J.b1, J.b4);
     for (int i = T - 1; i >= 0; --i) {
         PP_T(t0);
         pair_barrier(); // #1: the master has verified its guess of step i+1
@@ -864,8 +1018,17 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
             kk = X.kk2[lane];
             live = live_before && (X.ok[lane] != 0);
             gains(X.rdiag2[lane], X.free2[lane] != 0);
-            hand_over(i + 1);
+            hand_over(i + 1, J.b1, J.b4);
             pair_barrier(); // #1b
+        }
+        if (JAC_FROM_MASTER && i < T - 1) { // the Jacobian of step i-1, formed by the master during the step before
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Jn.a[r][c] = X.ja[r * 3 + c][lane];
+            Jn.b1 = X.ja[12][lane];
+            Jn.b4 = X.ja[13][lane];
         }
         PP_T(t1);
         PP_ADD(1, 0, t0, t1);
@@ -987,7 +1150,10 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
         }
         Quu = C.luu() + fma(M2[4], J.b4, M2[1] * J.b1);
         // ---- the Jacobian of step i-1 (operands xq, uq; its next state is x), while the master is still in its boxQP
-        cartpole_jac(P, xq, uq, x[2], x[3], J);
+        if (!JAC_FROM_MASTER) {
+            cartpole_jac(P, xq, uq, x[2], x[3], J);
+            Jn = J;
+        }
         PP_T(t2);
         PP_ADD(1, 1, t1, t2);
         pair_barrier(); // #2: the master's guess of k, factor and free mask of step i is in X
@@ -997,7 +1163,9 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
         live_before = live;
         live = live && (X.ok[lane] != 0);
         gains(X.rdiag[lane], X.free_[lane] != 0);
-        hand_over(i);
+        hand_over(i, Jn.b1, Jn.b4);
+        if (JAC_FROM_MASTER)
+            J = Jn;
         pending = true;
         PP_T(t4);
         PP_ADD(1, 3, t3, t4);
@@ -1052,7 +1220,7 @@ constexpr int LS_MAXA = 32;  // largest alpha schedule
 // below, wavefront 1 its helper in the backward sweeps (see pair_master_sweep).
 struct NoPair {
 };
-template <class Cost, bool PAIR>
+template <class Cost, int GROUP>
 __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, SolveOptsP O, BoundsP bd, int T,
                                                 int64_t B, SolveBuffers W,
                                                 double* __restrict__ delta_io,
@@ -1064,6 +1232,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     __shared__ double s_J[4][LS_PASS][LS_MAXA];
     __shared__ int s_lane[4][LS_PASS], s_cur[4][LS_PASS], s_gcur[4][LS_PASS];
     __shared__ double s_qp_tab[QP_TAB];
+    constexpr bool PAIR = GROUP >= 2; // wavefront 0 is the master; 1 the helper; 2 (GROUP == 3) the verifier
     __shared__ typename std::conditional<PAIR, PairX, NoPair>::type s_pair;
 
     // problems per wavefront (64, 32 or 16): a small batch is spread thinly over all SIMDs, which costs a
@@ -1126,8 +1295,21 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                     break;
                 const bool act = s_pair.act[lane] != 0;
                 const int pc = s_pair.cur[lane], pg = s_pair.gnew[lane];
-                pair_helper_sweep(P, C, T, ld, bq, s_pair, lane, act, XS(pc), US(pc), s_pair.mu[lane], KG(pg));
+                pair_helper_sweep<Cost, GROUP == 3>(P, C, T, ld, bq, s_pair, lane, act, XS(pc), US(pc), s_pair.mu[lane],
+                                                    KG(pg));
                 __syncthreads(); // K is stored: the master's rollouts may read it
+            }
+            return;
+        }
+        if (GROUP == 3 && (threadIdx.x >> 6) == 2) { // the verifier
+            for (;;) {
+                __syncthreads();
+                if (s_pair.cmd == 0)
+                    break;
+                const bool act = s_pair.act[lane] != 0;
+                const int pc = s_pair.cur[lane], pg = s_pair.gnew[lane];
+                pair_verifier_sweep(QO, s_qp_tab, bd, T, ld, bq, s_pair, lane, act, US(pc), KF(pg));
+                __syncthreads(); // k is stored
             }
             return;
         }
@@ -1167,9 +1349,11 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     bool running = valid && O.max_iter > 0;
     const int n_more = O.n_alpha - 1; // candidates after alpha_0
 
+    PP_DECL;
     for (int it = 0; it < O.max_iter; ++it) {
         if (__ballot(running) == 0ull)
             break;
+        PP_T(ti0);
         BwAcc S;
         int stopped_at = -1;
         S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
@@ -1192,8 +1376,8 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                 __syncthreads();
                 BwAcc Sn;
                 int sa;
-                int rc = pair_master_sweep(C, QO, s_qp_tab, bd, T, ld, bq, s_pair, lane, want, US(cur), mu, KF(gnew),
-                                           Sn, sa);
+                int rc = pair_master_sweep<Cost, GROUP == 2>(C, QO, s_qp_tab, bd, T, ld, bq, s_pair, lane, want, US(cur),
+                                                             mu, KF(gnew), Sn, sa, P, XS(cur));
                 __syncthreads(); // the helper's K is stored
                 if (want) {
                     S = Sn;
@@ -1212,6 +1396,8 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                 }
             }
         }
+        PP_T(ti1);
+        PP_ADD(0, 5, ti0, ti1);
         if (running) {
             const double* xs = XS(cur);
             const double* us = US(cur);
@@ -1249,6 +1435,8 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                 }
             }
         }
+        PP_T(ti2);
+        PP_ADD(0, 6, ti1, ti2);
         // ---- remaining alphas of the problems that need them, LS_PASS problems per pass
         // (helper lanes read gains another lane of this wave has just stored)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1336,7 +1524,10 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
             if (stop || converged)
                 running = false;
         }
+        PP_T(ti3);
+        PP_ADD(0, 7, ti2, ti3);
     }
+    PP_FLUSH(0);
     if (valid) {
         delta_io[gb] = delta;
         J_out[gb] = J;
@@ -1920,13 +2111,19 @@ static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts,
     // full wave per workgroup and keep that shape.
     const bool short_launch = (int64_t)T * O.max_iter < 2048;
     int lpw = (B <= 32 * 1024 && !short_launch) ? 32 : WAVE;
-    // Long solves of up to 32768 problems run two wavefronts per group of problems (see pair_master_sweep): 32
-    // problems per group up to 16384 problems, 64 above, so that the 2 x 512 wavefronts still have a SIMD each.
-    // ILQR_SOLVE_PAIR=0/1 overrides the choice.
-    bool pair = !short_launch && B <= 32 * 1024;
-    if (const char* e = std::getenv("ILQR_SOLVE_PAIR"))
-        pair = e[0] == '1';
-    if (pair && B > 16 * 1024)
+    // Long solves of up to 32768 problems share each group's backward sweep between several wavefronts (see
+    // pair_master_sweep): three (master, helper, verifier) while 3 wavefronts per 64 problems still find a SIMD
+    // each, two above that; 32 problems per group while even that many wavefronts have a SIMD each, 64 otherwise.
+    // ILQR_SOLVE_GROUP=1/2/3 overrides the choice.
+    int group = 1; // wavefronts per group of problems
+    if (!short_launch && B <= 32 * 1024)
+        group = ((B + 63) / 64) * 3 <= 1024 ? 3 : 2;
+    if (const char* e = std::getenv("ILQR_SOLVE_GROUP")) {
+        int v = std::atoi(e);
+        group = (v >= 1 && v <= 3) ? v : group;
+    }
+    const bool pair = group >= 2;
+    if (pair && ((B + 31) / 32) * group > 1024) // a SIMD for every wavefront, or full wavefronts
         lpw = WAVE;
     if (const char* e = std::getenv("ILQR_SOLVE_LPW")) {
         int v = std::atoi(e);
@@ -1944,17 +2141,20 @@ static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts,
     }
     dim3 grid((unsigned)((nwaves * WAVE + blk - 1) / blk));
     if (pair) {
-        blk = 2 * WAVE;
+        blk = group * WAVE;
         grid = dim3((unsigned)((nwaves + 15) / 16 * 16)); // whole chunks of 16 groups (the kernel's group <-> workgroup map)
     }
     int ev = cost_eval(C);
 #define ILQR_LAUNCH_SOLVE(COST)                                                                                  \
     do {                                                                                                         \
-        if (pair)                                                                                                \
-            hipLaunchKernelGGL((k_solve<COST, true>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu, \
+        if (group == 3)                                                                                          \
+            hipLaunchKernelGGL((k_solve<COST, 3>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu,    \
+                               iters, status, tr);                                                               \
+        else if (group == 2)                                                                                     \
+            hipLaunchKernelGGL((k_solve<COST, 2>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J, mu,    \
                                iters, status, tr);                                                               \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_solve<COST, false>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J,    \
+            hipLaunchKernelGGL((k_solve<COST, 1>), grid, dim3(blk), 0, st, mp, C, O, bd, (int)T, B, W, delta, J,        \
                                mu, iters, status, tr);                                                           \
     } while (0)
     if (ev == EVAL_DIAG)
@@ -2267,12 +2467,12 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
 }
 
 #ifdef ILQR_PAIR_PROF
-int ilqr_debug_pair_prof(unsigned long long* host16, int reset)
+int ilqr_debug_pair_prof(unsigned long long* host24, int reset)
 {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     if (reset)
         return hip_status(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_prof), z, sizeof(z)));
-    return hip_status(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_pair_prof), sizeof(z)));
+    return hip_status(hipMemcpyFromSymbol(host24, HIP_SYMBOL(g_pair_prof), sizeof(z)));
 }
 #endif
 

@@ -177,9 +177,10 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
  *   out: xs [B,T+1,n], us [B,T,m], J [B], mu [B], iters [B], status [B] (ILQR_RAN_OUT..)
  *   trace: NULL or device arrays as described at ilqr_trace.
  *   workspace: device buffer of at least ilqr_solve_workspace_bytes(model, B).
- * The launch shape (problems per wavefront, wavefronts per workgroup) is chosen from B, T and
- * max_iter and never changes a result; for experiments the environment variables ILQR_SOLVE_LPW
- * (16, 32 or 64) and ILQR_SOLVE_BLOCK (64, 128 or 256 threads) override it. */
+ * The launch shape (problems per wavefront, wavefronts per workgroup, and how many wavefronts share the
+ * backward sweep of one group of problems) is chosen from B, T and max_iter and never changes a result; for
+ * experiments the environment variables ILQR_SOLVE_LPW (16, 32 or 64), ILQR_SOLVE_BLOCK (64, 128 or 256
+ * threads) and ILQR_SOLVE_GROUP (1, 2 or 3 wavefronts per group) override it. */
 size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B);
 int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
                        const double* us_init, double* delta, double* k, double* K, double* xs,

@@ -602,19 +602,21 @@ def test_c_level_chunked_solve_equals_single_launch(hip, B, chunk):
 
 
 def test_every_launch_shape_gives_the_same_bits(hip):
-    """Problems per wavefront, wavefronts per workgroup, and one or two wavefronts per group of problems (the
-    backward sweep shared between a master and a helper wavefront) only change which lane computes what."""
+    """Problems per wavefront, wavefronts per workgroup, and one, two or three wavefronts per group of problems
+    (the backward sweep shared between a master, a helper and a verifier wavefront) only change which lane
+    computes what."""
     import os
     Mo = co.cartpole_model(T=40)
     M = hip_model(hip, Mo)
     B = 333  # ragged: the last wavefront and the last workspace tile are partly empty in every shape
     x0, us0 = co.cartpole_batch(B, T=Mo.T, seed_x=91, seed_u=92)
     ref = co.solve(Mo, co.Opts(max_iter=40), x0, us0, nthreads=8)
-    names = ("ILQR_SOLVE_LPW", "ILQR_SOLVE_BLOCK", "ILQR_SOLVE_PAIR")
+    names = ("ILQR_SOLVE_LPW", "ILQR_SOLVE_BLOCK", "ILQR_SOLVE_GROUP")
     saved = {k: os.environ.get(k) for k in names}
     try:
-        for shape in ((None, None, None), (64, 64, 0), (64, 128, 0), (64, 256, 0), (32, 128, 0), (32, 256, 0),
-                      (16, 256, 0), (64, None, 1), (32, None, 1), (16, None, 1)):
+        for shape in ((None, None, None), (64, 64, 1), (64, 128, 1), (64, 256, 1), (32, 128, 1), (32, 256, 1),
+                      (16, 256, 1), (64, None, 2), (32, None, 2), (16, None, 2), (64, None, 3), (32, None, 3),
+                      (16, None, 3)):
             for key, val in zip(names, shape):
                 if val is None:
                     os.environ.pop(key, None)
@@ -676,14 +678,14 @@ def test_backward_pass_giving_up_at_mu_max_reuses_the_previous_sums_across_launc
             assert torch.equal(one[key], ch[key]), (chunk, key)
 
 
-@pytest.mark.parametrize("pair", ["1", "0"])
-def test_two_wavefront_sweep_on_the_rare_paths(hip, monkeypatch, pair):
-    """The backward sweep shared by two wavefronts (long solves of up to 32768 problems take it by default;
-    forced here on short ones) through the paths a swing-up batch rarely visits: the LinAlgError retry loop
+@pytest.mark.parametrize("group", ["3", "2", "1"])
+def test_shared_backward_sweep_on_the_rare_paths(hip, monkeypatch, group):
+    """The backward sweep shared by three or two wavefronts (long solves of up to 32768 problems take it by
+    default; forced here on short ones) through the paths a swing-up batch rarely visits: the LinAlgError retry loop
     that gives up at mu_max, non-PD breaks (ilqr_core.py:137-140), wrong guesses of the boxQP outcome (the
     warm-started re-solves of a closed loop end their boxQP on other paths than a cold solve), and lanes
     that leave the loop at different iterations."""
-    monkeypatch.setenv("ILQR_SOLVE_PAIR", pair)  # ("0": the same paths through the one-wavefront sweep)
+    monkeypatch.setenv("ILQR_SOLVE_GROUP", group)  # ("1": the same paths through the one-wavefront sweep)
     # (a) giving up at mu_max, with non-PD breaks on the way (see the test of that name above)
     B, T = 70, 6
     Mo = co.cartpole_model(T=T, dt=1.5)
