@@ -148,6 +148,29 @@ __device__ __forceinline__ void cartpole_f(const CartpoleC& P, const double (&x)
     out[4] = thd + thdd * P.dt;
 }
 
+// The same expression in two independent halves (a step's next velocities do not depend on its next angle
+// and vice versa), for a rollout shared by two wavefronts: same operations, same bits.
+__device__ __forceinline__ void cartpole_f_velocities(const CartpoleC& P, const double (&x)[NX], double F,
+                                                      double& out0, double& out1, double& out4)
+{
+    double xd = x[1], s = x[2], c = x[3], thd = x[4];
+    double temp = (F + P.mpl * (thd * thd) * s) / P.M;
+    double num = P.g * s - c * temp;
+    double den = P.l * (4.0 / 3.0 - P.mp * (c * c) / P.M);
+    double thdd = num / den;
+    double xdd = temp - P.mpl * thdd * c / P.M;
+    out0 = x[0] + xd * P.dt;
+    out1 = xd + xdd * P.dt;
+    out4 = thd + thdd * P.dt;
+}
+__device__ __forceinline__ void cartpole_f_angle(const CartpoleC& P, double s, double c, double thd, double& sn,
+                                                 double& cn)
+{
+    double th = det_atan2(s, c);
+    double nth = th + thd * P.dt;
+    det_sincos(nth, sn, cn);
+}
+
 // Non-trivial entries of f_x (rows 1..4, columns 2..4) and f_u (rows 1, 4).
 //   f_x = [1 dt 0   0   0  ]   f_u = [0 ]
 //         [0 1  a12 a13 a14]         [b1]

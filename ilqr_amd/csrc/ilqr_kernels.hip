@@ -665,6 +665,7 @@ struct PairX {
     double dJ[2][64];         // per sweep, verifier -> master (three wavefronts): Delta_J1, Delta_J2 ...
     int cnt[3][64];           // ... and the boxQP counters
     double ja[14][64];        // master -> helper (three wavefronts): the Jacobian of the step after next
+    double fw[2][3][64];      // shared rollout (two sets, used in turn): helper -> master sin, cos of the next angle; master -> helper its rate
 };
 
 // LDS hand-over between the two wavefronts of a pair: waits for LDS only, so global loads issued ahead
@@ -677,7 +678,7 @@ __device__ __forceinline__ void pair_barrier()
 }
 
 #ifdef ILQR_PAIR_PROF // diagnostic build only: shader clocks of the two halves of the shared backward sweep
-static __device__ unsigned long long g_pair_prof[3][8];
+static __device__ unsigned long long g_pair_prof[4][8];
 #define PP_DECL unsigned long long pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PP_T(var) const long long var = __builtin_amdgcn_s_memtime()
 #define PP_ADD(role, slot, a, bq) pp_acc[slot] += (unsigned long long)((bq) - (a))
@@ -693,6 +694,107 @@ static __device__ unsigned long long g_pair_prof[3][8];
 #define PP_COUNT(role, slot)
 #define PP_FLUSH(role)
 #endif
+
+// The accepted-step rollout (alpha_0, with stores) shared by two wavefronts that hold the same problems lane for
+// lane.  Within a step the next angle (atan2 of the stored sin/cos, plus rate x dt, then sin/cos: one long chain
+// of dependent operations) and the next velocities (control law, accelerations) do not depend on one another;
+// each needs the other's result of the step before.  The master keeps everything forward_rollout does except the
+// angle; the helper runs the angle chain; they swap three numbers per lane and step through LDS.
+template <class Cost>
+__device__ __forceinline__ double forward_rollout_master(const CartpoleC& P, const Cost& C, int T, int64_t ld, int64_t b,
+                                                         PairX& X, int lane, const double* __restrict__ xs,
+                                                         const double* __restrict__ us, const double* __restrict__ k,
+                                                         const double* __restrict__ K, double alpha,
+                                                         double* __restrict__ xs_new, double* __restrict__ us_new)
+{
+    struct Ops {
+        double xo[NX], Kr[NX], u, kk;
+    };
+    auto fetch = [&](int t, Ops& o) {
+        load5(xs, ld, (int64_t)t * NX, b, o.xo);
+        load5(K, ld, (int64_t)t * NX, b, o.Kr);
+        o.u = us[(int64_t)t * ld + b];
+        o.kk = k[(int64_t)t * ld + b];
+    };
+    double xn[NX], xt[NX];
+    load5(xs, ld, 0, b, xn);
+    double J = 0.0;
+    Ops cur, nxt;
+    fetch(0, cur);
+    fetch(T > 1 ? 1 : 0, nxt);
+    double pend_x[NX], pend_u = 0.0;
+#pragma unroll
+    for (int a = 0; a < NX; ++a)
+        pend_x[a] = xn[a];
+    PP_DECL;
+    PP_T(tf0);
+#pragma unroll 2
+    for (int t = 0; t < T; ++t) {
+        Ops far;
+        fetch(t + 2 < T ? t + 2 : T - 1, far);
+        {
+            int ts = t > 0 ? t - 1 : 0;
+            store5(xs_new, ld, (int64_t)ts * NX, b, pend_x);
+            us_new[(int64_t)ts * ld + b] = pend_u;
+        }
+        double un = fw_control(xn, cur.xo, cur.u, cur.kk, cur.Kr, alpha);
+        cartpole_f_velocities(P, xn, un, xt[0], xt[1], xt[4]);
+        X.fw[t & 1][2][lane] = xt[4];
+        C.at(t);
+        J = J + C.l(xn, un);
+        PP_T(tf1);
+        pair_barrier();
+        PP_T(tf2);
+        PP_ADD(3, 1, tf1, tf2);
+        xt[2] = X.fw[t & 1][0][lane];
+        xt[3] = X.fw[t & 1][1][lane];
+#pragma unroll
+        for (int a = 0; a < NX; ++a)
+            keep_alive(pend_x[a]);
+        keep_alive(pend_u);
+        pend_u = un;
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+            pend_x[a] = xn[a];
+            xn[a] = xt[a];
+        }
+        cur = nxt;
+        nxt = far;
+    }
+    PP_T(tf3);
+    PP_ADD(3, 0, tf0, tf3);
+    PP_FLUSH(3);
+    store5(xs_new, ld, (int64_t)(T - 1) * NX, b, pend_x);
+    us_new[(int64_t)(T - 1) * ld + b] = pend_u;
+    store5(xs_new, ld, (int64_t)T * NX, b, xn);
+    C.at_terminal(T);
+    return J + C.l_terminal(xn);
+}
+
+__device__ __forceinline__ void forward_rollout_helper(const CartpoleC& P, int T, int64_t ld, int64_t b, PairX& X, int lane,
+                                                       const double* __restrict__ xs)
+{
+    double s = xs[2 * ld + b], c = xs[3 * ld + b], thd = xs[4 * ld + b];
+    PP_DECL;
+    PP_T(tf0);
+    for (int t = 0; t < T; ++t) {
+        double sn, cn;
+        cartpole_f_angle(P, s, c, thd, sn, cn);
+        X.fw[t & 1][0][lane] = sn;
+        X.fw[t & 1][1][lane] = cn;
+        PP_T(tf1);
+        pair_barrier();
+        PP_T(tf2);
+        PP_ADD(3, 3, tf1, tf2);
+        thd = X.fw[t & 1][2][lane];
+        s = sn;
+        c = cn;
+    }
+    PP_T(tf3);
+    PP_ADD(3, 2, tf0, tf3);
+    PP_FLUSH(3);
+}
+
 
 // Master half of one backward sweep.  act: the lane takes part (its problem still needs this backward pass).
 // S receives Delta_J and the boxQP counters; k [T, ld] is written for the lanes that take part (zeros where
@@ -1118,6 +1220,15 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
                 M1[(2 + c) * NX + bb] = acc;
             }
         }
+#if defined(ILQR_PIN_M1)
+        // (with three wavefronts the hand-over of the guess waits for the verifier's first boxQP pass: this much of
+        // the Q-terms fits in front of it)
+#pragma unroll
+        for (int a = 1; a < NX; ++a)
+#pragma unroll
+            for (int bb = 0; bb < NX; ++bb)
+                asm volatile("" : "+v"(M1[a * NX + bb]));
+#endif
 #pragma unroll
         for (int a = 0; a < NX; ++a) {
             Qxx[a * NX + 0] = C.add_lxx(a, 0, M1[a * NX + 0]);
@@ -1149,6 +1260,22 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
             Qux[2 + c] = 0.0 + acc;
         }
         Quu = C.luu() + fma(M2[4], J.b4, M2[1] * J.b1);
+#if !defined(ILQR_NO_PIN_QUX)
+        // (what the gains wait for after the hand-over of the guess: ready before it)
+#pragma unroll
+        for (int bb = 0; bb < NX; ++bb)
+            asm volatile("" : "+v"(Qux[bb]));
+        asm volatile("" : "+v"(Quu));
+#endif
+#if defined(ILQR_PIN_SIX)
+        asm volatile("" : "+v"(Qxx[1 * NX + 1]));
+        asm volatile("" : "+v"(Qxx[1 * NX + 4]));
+        asm volatile("" : "+v"(Qxx[4 * NX + 1]));
+        asm volatile("" : "+v"(Qxx[4 * NX + 4]));
+        asm volatile("" : "+v"(Qx[1]));
+        asm volatile("" : "+v"(Qx[4]));
+        asm volatile("" : "+v"(Qu));
+#endif
         // ---- the Jacobian of step i-1 (operands xq, uq; its next state is x), while the master is still in its boxQP
         if (!JAC_FROM_MASTER) {
             cartpole_jac(P, xq, uq, x[2], x[3], J);
@@ -1291,10 +1418,15 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         if ((threadIdx.x >> 6) == 1) { // the helper: one backward sweep per command of the master
             for (;;) {
                 __syncthreads(); // the master's command, and its stores to the trajectory (global memory)
-                if (s_pair.cmd == 0)
+                const int cmd = s_pair.cmd;
+                if (cmd == 0)
                     break;
                 const bool act = s_pair.act[lane] != 0;
                 const int pc = s_pair.cur[lane], pg = s_pair.gnew[lane];
+                if (cmd == 2) { // the angle chain of the master's rollout
+                    forward_rollout_helper(P, T, ld, bq, s_pair, lane, XS(pc));
+                    continue;
+                }
                 pair_helper_sweep<Cost, GROUP == 3>(P, C, T, ld, bq, s_pair, lane, act, XS(pc), US(pc), s_pair.mu[lane],
                                                     KG(pg));
                 __syncthreads(); // K is stored: the master's rollouts may read it
@@ -1304,8 +1436,14 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         if (GROUP == 3 && (threadIdx.x >> 6) == 2) { // the verifier
             for (;;) {
                 __syncthreads();
-                if (s_pair.cmd == 0)
+                const int cmd = s_pair.cmd;
+                if (cmd == 0)
                     break;
+                if (cmd == 2) { // a rollout shared by the other two: only their hand-overs to attend
+                    for (int t = 0; t < T; ++t)
+                        pair_barrier();
+                    continue;
+                }
                 const bool act = s_pair.act[lane] != 0;
                 const int pc = s_pair.cur[lane], pg = s_pair.gnew[lane];
                 pair_verifier_sweep(QO, s_qp_tab, bd, T, ld, bq, s_pair, lane, act, US(pc), KF(pg));
@@ -1398,6 +1536,14 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         }
         PP_T(ti1);
         PP_ADD(0, 5, ti0, ti1);
+        if constexpr (PAIR) {
+            if (O.n_alpha > 0) { // the first rollout is shared with the helper wavefront
+                s_pair.cur[lane] = cur;
+                if (lane == 0)
+                    s_pair.cmd = 2;
+                __syncthreads();
+            }
+        }
         if (running) {
             const double* xs = XS(cur);
             const double* us = US(cur);
@@ -1422,7 +1568,11 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
             // ---- line search, alpha_0 (:301-313)
             if (O.n_alpha > 0) {
                 double alpha = s_alpha[0];
-                Jnew = forward_rollout<true>(P, C, T, ld, b, xs, us, KF(gcur), KG(gcur), alpha, XS(nxt), US(nxt));
+                if constexpr (PAIR)
+                    Jnew = forward_rollout_master(P, C, T, ld, b, s_pair, lane, xs, us, KF(gcur), KG(gcur), alpha, XS(nxt),
+                                                  US(nxt));
+                else
+                    Jnew = forward_rollout<true>(P, C, T, ld, b, xs, us, KF(gcur), KG(gcur), alpha, XS(nxt), US(nxt));
                 double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
                 if (expected <= 0.0) {
                     // reject the whole iteration
@@ -2467,12 +2617,12 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
 }
 
 #ifdef ILQR_PAIR_PROF
-int ilqr_debug_pair_prof(unsigned long long* host24, int reset)
+int ilqr_debug_pair_prof(unsigned long long* host32, int reset)
 {
-    unsigned long long z[24] = {0};
+    unsigned long long z[32] = {0};
     if (reset)
         return hip_status(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_prof), z, sizeof(z)));
-    return hip_status(hipMemcpyFromSymbol(host24, HIP_SYMBOL(g_pair_prof), sizeof(z)));
+    return hip_status(hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_pair_prof), sizeof(z)));
 }
 #endif
 
