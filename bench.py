@@ -314,7 +314,11 @@ def cartpole_roofline(B, iters, kernel_ms, chunked):
         # up to 32768 problems every wavefront has a SIMD to itself and the time is the latency of one
         # wavefront's instruction stream: the resource in use is VALU issue
         roof = {"bound": "fp64_valu_issue", "unit": "fraction of the chip's SIMD cycles with a VALU instruction "
-                                                    "in flight", "peak": 1.0}
+                                                    "in flight", "peak": 1.0,
+                "note": "at this batch size the time is the latency of the dependent fp64 chains of one group of "
+                        "problems (spread over up to three wavefronts on three SIMDs of a CU); neither VALU issue "
+                        "nor HBM is saturated, and the fraction says how much of the chip's issue capacity the "
+                        "launch uses, not how close the kernel is to a limit"}
         if cnt and cnt.get("valu_busy_frac_of_chip") is not None:
             roof.update(achieved=cnt["valu_busy_frac_of_chip"], frac=cnt["valu_busy_frac_of_chip"],
                         valu_busy_frac_per_wave=cnt.get("valu_busy_frac_per_wave"),
