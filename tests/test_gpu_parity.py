@@ -733,3 +733,39 @@ def test_shared_backward_sweep_on_the_rare_paths(hip, monkeypatch, group):
                      K=dev(ref["K"]), trace=True)
     same(out2, ref2, B)
     assert len(np.unique(ref["iters"])) > 3
+
+
+@pytest.mark.parametrize("group", ["3", "2", "1"])
+def test_shortest_horizons_and_option_corners_through_every_sweep_variant(hip, monkeypatch, group):
+    """Horizons of one, two and three steps (the shared sweeps hand operands over two steps ahead), a single
+    problem, a single step size (no further candidates to try), zero iterations, and a dense cost matrix."""
+    monkeypatch.setenv("ILQR_SOLVE_GROUP", group)
+    for T, B in ((1, 5), (2, 70), (3, 1), (4, 129)):
+        Mo = co.cartpole_model(T=T)
+        x0, us0 = co.cartpole_batch(B, T=T, seed_x=40 + T, seed_u=50 + T)
+        _check_solve(hip, Mo, x0, us0, 30)
+    # one step size only: an iteration whose first rollout is rejected is rejected as a whole
+    T, B = 12, 90
+    Mo = co.cartpole_model(T=T)
+    M = hip_model(hip, Mo)
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=61, seed_u=62)
+    for n_alpha in (1, 2):
+        kw = dict(max_iter=40, line_search_steps=n_alpha, scale=0.97)  # (a demanding accept ratio: rejections occur)
+        ref = co.solve(Mo, co.Opts(**kw), x0, us0, nthreads=8)
+        out = hip.solve(M, hip.Opts(**kw), dev(x0), dev(us0), trace=True)
+        assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+        for key in ("J", "xs", "us", "k", "K", "mu", "delta"):
+            assert eq(out[key].cpu().numpy(), ref[key]), (n_alpha, key)
+        assert (ref["trace"]["accepted"] == 0).any()
+    # zero iterations: the initial rollout and its cost
+    ref = co.solve(Mo, co.Opts(max_iter=0), x0, us0, nthreads=8)
+    out = hip.solve(M, hip.Opts(max_iter=0), dev(x0), dev(us0))
+    for key in ("J", "xs", "us"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+    assert (out["iters"].cpu().numpy() == 0).all()
+    # a full (non-symmetric) Q: the dense cost evaluator in the shared sweeps
+    r = np.random.RandomState(7)
+    Mf = co.Model(co.MODEL_CARTPOLE, 5, 1, T, co.COST_QR, co.MATH_DET, True, Q=Mo.Q + r.uniform(-2, 2, (5, 5)), R=Mo.R,
+                  Q_terminal=Mo.Qt + r.uniform(-2, 2, (5, 5)), x_goal=Mo.x_goal, u_goal=[0.3], lower=Mo.lower,
+                  upper=Mo.upper)
+    _check_solve(hip, Mf, x0, us0, 25)
