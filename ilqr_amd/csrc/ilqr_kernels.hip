@@ -1635,9 +1635,21 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
             __builtin_amdgcn_wave_barrier();
             mask = __ballot(need);
         }
-        if (redo) // the accepted candidate's states and controls (same arithmetic, same bits)
+        // the accepted candidate's states and controls (same arithmetic, same bits)
+        if constexpr (PAIR) {
+            if (__ballot(redo) != 0ull) { // shared with the helper wavefront like the first rollout
+                s_pair.cur[lane] = cur;
+                if (lane == 0)
+                    s_pair.cmd = 2;
+                __syncthreads();
+                if (redo)
+                    Jnew = forward_rollout_master(P, C, T, ld, b, s_pair, lane, XS(cur), US(cur), KF(gcur), KG(gcur),
+                                                  s_alpha[j], XS(nxt), US(nxt));
+            }
+        } else if (redo) {
             Jnew = forward_rollout<true>(P, C, T, ld, b, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(nxt),
                                          US(nxt));
+        }
         // ---- regularisation schedule and termination (:315-339)
         if (running) {
             bool stop = false;
@@ -2261,20 +2273,32 @@ static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts,
     // full wave per workgroup and keep that shape.
     const bool short_launch = (int64_t)T * O.max_iter < 2048;
     int lpw = (B <= 32 * 1024 && !short_launch) ? 32 : WAVE;
-    // Solves of up to 32768 problems share each group's backward sweep and first rollout between several wavefronts (see
-    // pair_master_sweep): three (master, helper, verifier) while 3 wavefronts per 64 problems still find a SIMD
-    // each, two above that; 32 problems per group while even that many wavefronts have a SIMD each, 64 otherwise.
-    // ILQR_SOLVE_GROUP=1/2/3 overrides the choice.
+    // Solves that leave SIMDs idle share each group's backward sweep and first rollout between several wavefronts
+    // of one workgroup (see pair_master_sweep).  A workgroup's wavefronts need a SIMD each on ONE CU (the kernel's
+    // register count allows one wavefront per SIMD), so a CU holds one group of three (master, helper, verifier)
+    // or two groups of two; groups that find no CU would wait for a second round.  Hence: three wavefronts per
+    // group while the groups number at most the CUs, two while at most twice the CUs; 32 problems per group while
+    // even that many groups fit, 64 otherwise.  ILQR_SOLVE_GROUP=1/2/3 overrides the choice.
+    int n_cu = 256;
+    {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n_cu = v;
+    }
+    const int64_t groups64 = (B + 63) / 64, groups32 = (B + 31) / 32;
     int group = 1; // wavefronts per group of problems
-    if (B <= 32 * 1024) // (short launches gain as much: a closed-loop control step 0.19 -> 0.145 ms at 4096 loops)
-        group = ((B + 63) / 64) * 3 <= 1024 ? 3 : 2;
+    if (groups64 <= n_cu)
+        group = 3;
+    else if (groups64 <= 2 * (int64_t)n_cu)
+        group = 2;
     if (const char* e = std::getenv("ILQR_SOLVE_GROUP")) {
         int v = std::atoi(e);
         group = (v >= 1 && v <= 3) ? v : group;
     }
     const bool pair = group >= 2;
     if (pair)
-        lpw = ((B + 31) / 32) * group > 1024 ? WAVE : 32; // a SIMD for every wavefront, or full wavefronts
+        lpw = groups32 <= (group == 3 ? 1 : 2) * (int64_t)n_cu ? 32 : WAVE;
     if (const char* e = std::getenv("ILQR_SOLVE_LPW")) {
         int v = std::atoi(e);
         lpw = (v == 16 || v == 32) ? v : WAVE;
