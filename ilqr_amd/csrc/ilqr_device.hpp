@@ -933,8 +933,8 @@ __device__ __forceinline__ void boxqp1(const QPOptsP& O, const double* tab, doub
     out.n_backtrack = (act0 ? n0 : 0) + (exh1 ? O.n_exhaust : 0);
 }
 
-// The outcome of boxqp1 on its most common path, by the shortest chain of dependent operations: pass 0 jumps
-// to trip t_j and accepts, pass 1 accepts the full Newton step, pass 2 ends on a termination test.  Same
+// The outcome of boxqp1 on its most common paths, by the shortest chain of dependent operations: pass 0 jumps
+// to trip t_j and accepts, pass 1 leaves at once or accepts the full Newton step, pass 2 ends on a termination test.  Same
 // expressions as boxqp1 (a compiler merges the two), none of its checks: the caller must compare with boxqp1.
 __device__ __forceinline__ void boxqp1_guess(const QPOptsP& O, const double* tab, double H, double rsqrtH, double g,
                                              double lo, double hi, double x0, double& x_out, bool& free_out)
@@ -962,8 +962,13 @@ __device__ __forceinline__ void boxqp1_guess(const QPOptsP& O, const double* tab
     const double xc = fmax(lo, fmin(hi, xb + 1.0 * search1));
     const double grad2 = g + H * xc;
     const bool cl2 = ((xc == lo) & (grad2 > 0.0)) | ((xc == hi) & (grad2 < 0.0));
-    x_out = xc;
-    free_out = !cl2;
+    // (beside the chain: a call that leaves at the start of pass 1 -- on a limit with the gradient pointing outwards,
+    // or with a gradient below the threshold -- returns the candidate of pass 0)
+    const double grad1 = g + H * xb;
+    const bool cl1 = ((xb == lo) & (grad1 > 0.0)) | ((xb == hi) & (grad1 < 0.0));
+    const bool left1 = cl1 | (fabs(grad1) < O.min_grad);
+    x_out = left1 ? xb : xc;
+    free_out = left1 ? !cl1 : !cl2;
 }
 
 // ---- backward step ----------------------------------------------------------
