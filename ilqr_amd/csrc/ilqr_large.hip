@@ -185,6 +185,19 @@ struct QPR {
     bool linalg;
 };
 
+// Q_uu (8 x 8) of the wave's problem with entry e held by lane e: one register for the whole matrix, and an
+// entry is a lane read (two scalar moves) instead of an LDS load whose latency every dependent chain of the
+// boxQP would wait for.
+struct HLanes {
+    double v;
+    __device__ __forceinline__ double operator[](int e) const
+    {
+        int lo = __builtin_amdgcn_readlane(__double2loint(v), e);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(v), e);
+        return __hiloint2double(hi, lo);
+    }
+};
+
 // The free set as a scalar bit mask: every lane of the wave holds the same problem, so the mask is
 // wave-uniform and a test of one of its bits is a scalar branch (clamped rows and columns are then
 // skipped instead of computed and discarded; what is skipped are exact zeros and the unused pivots).
@@ -198,7 +211,8 @@ __device__ __forceinline__ unsigned lr_mask(const bool (&fr)[LM])
 }
 
 // Lower Cholesky factor of H restricted to the free set; returns true if a free pivot is not > 0.
-__device__ __forceinline__ bool lr_chol(const double* H, const bool (&fr)[LM], double (&Lf)[LM][LM], double (&rd)[LM])
+template <class HT>
+__device__ __forceinline__ bool lr_chol(const HT& H, const bool (&fr)[LM], double (&Lf)[LM][LM], double (&rd)[LM])
 {
     const unsigned fm = lr_mask(fr);
     bool fail = false;
@@ -277,7 +291,8 @@ __device__ __forceinline__ void lr_solve_ones(double (&b)[LM])
     }
 }
 
-__device__ __forceinline__ double lr_value(const double* H, const double* g, const double (&x)[LM])
+template <class HT>
+__device__ __forceinline__ double lr_value(const HT& H, const double* g, const double (&x)[LM])
 {
     double xg = x[0] * g[0];
 #pragma unroll
@@ -295,8 +310,9 @@ __device__ __forceinline__ double lr_value(const double* H, const double* g, con
     return xg + 0.5 * tot;
 }
 
-// H [64] (LDS, finite and positive definite: the caller has checked; a copy in registers was measured:
-// what the boxQP gains, the matrix part loses to spills), steps: the wave's step table.
+// H: Q_uu, finite and positive definite (the caller has checked), entry e on lane e (HLanes; a copy of all 64
+// entries in registers was measured: what the boxQP gains, the matrix part loses to spills; read from LDS entry by
+// entry the solve of 8192 problems takes 705 instead of 669 ms); steps: the wave's step table.
 // On entry Q.x holds the warm start and Q.Lf / Q.rd / Q.fmask the factor of the full H (the caller
 // needed it for the warm start): a factorisation for a free set that Lf already belongs to is not
 // repeated (same inputs, same bits); the reference's counter still counts it.
@@ -309,7 +325,8 @@ static __device__ unsigned long long g_lqp[8];
 #define LQP_ADD(slot, a, b)
 #endif
 
-__device__ void lr_boxqp(const LQPOpts& O, const double* H, const double* steps, QPR& Q)
+template <class HT>
+__device__ void lr_boxqp(const LQPOpts& O, const HT& H, const double* steps, QPR& Q)
 {
 #ifdef ILQR_LARGE_QP_PROF
     unsigned long long lqp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -732,10 +749,8 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         }
         long long t_b = prof ? clock64() : 0;
         // np.all(np.linalg.eigvals(Q_uu) > 0) else print / warn / break   (:137-140)
-        bool finite = true;
-#pragma unroll
-        for (int a = 0; a < LM * LM; ++a)
-            finite = finite && (fabs(S.H[a]) < __builtin_inf());
+        const HLanes Hq{S.H[lane & 63]};
+        const bool finite = __ballot(!(fabs(Hq.v) < __builtin_inf())) == 0ull;
         if (!finite) {
             out.rc = 2;
             break;
@@ -749,7 +764,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 #pragma unroll
             for (int a = 0; a < LM; ++a)
                 all_free[a] = true;
-            if (lr_chol(S.H, all_free, qr.Lf, qr.rd)) {
+            if (lr_chol(Hq, all_free, qr.Lf, qr.rd)) {
                 out.stopped_at = i;
                 break;
             }
@@ -761,7 +776,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
             qr.fmask = 0xffu;
         }
         long long t_b1 = prof ? clock64() : 0;
-        lr_boxqp(QO, S.H, M.steps, qr);
+        lr_boxqp(QO, Hq, M.steps, qr);
         long long t_b2 = prof ? clock64() : 0;
         if (qr.linalg) {
             out.rc = 2;
@@ -885,10 +900,10 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
             double d2 = 0.0;
 #pragma unroll
             for (int a = 0; a < LM; ++a) {
-                double acc = S.H[a * LM] * kq[0];
+                double acc = Hq[a * LM] * kq[0];
 #pragma unroll
                 for (int c = 1; c < LM; ++c)
-                    acc = fma(S.H[a * LM + c], kq[c], acc);
+                    acc = fma(Hq[a * LM + c], kq[c], acc);
                 d2 = (a == 0) ? kq[0] * acc : fma(kq[a], acc, d2);
             }
             out.dJ1 = out.dJ1 + d1;
