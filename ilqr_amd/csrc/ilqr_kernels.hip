@@ -627,10 +627,10 @@ __global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP Cp, A
     Jnew[(int64_t)ai * ld + b] = forward_rollout<STORE>(P, C, T, ld, b, xs, us, k, K, al.a[ai], xo, uo);
 }
 
-// ------------------------------------------- backward pass shared by two wavefronts
+// ------------------------------------------- sweeps shared by two or three wavefronts
 //
-// Up to 32768 problems every wavefront has a SIMD to itself and the solve takes as long as ONE wavefront
-// needs for its instruction stream; most of that is the backward sweep's serial chain
+// While a batch leaves SIMDs idle the solve takes as long as ONE wavefront needs for its instruction stream;
+// most of that is the backward sweep's serial chain
 //     V  ->  Q_uu, Q_u  ->  Cholesky, boxQP  ->  k, K  ->  V of the step before,
 // of which the boxQP's three passes alone are ~450 instructions that depend on one another (a dependent fp64
 // operation issues every ~8 cycles).  With SIMDs to spare the sweep is cut between two wavefronts that hold
@@ -651,6 +651,11 @@ __global__ __launch_bounds__(WAVE) void k_forward_ls(CartpoleP mp, QRCostP Cp, A
 // Hand-overs per step: #2 master -> helper (the guess), #1 helper -> master (six numbers + f_u of the step
 // before + the master's verdict on the previous guess), #1b only after a wrong guess.  Every number is
 // computed by the expression the one-wavefront sweep uses, hence the same bits.
+// With a third wavefront per group (pair_verifier_sweep) the verification leaves the master as well: the verifier
+// reads the same hand-over, runs boxqp1, meets the other two at #2 between its first and second pass and raises
+// the flag; the master, idle after its guess, forms the Jacobians two steps ahead for the helper (X.ja).
+// The first rollout of an iteration is shared too (forward_rollout_master / forward_rollout_helper): the helper
+// runs the chain atan2 -> next angle -> sin, cos, the master everything else of a step.
 struct PairX {
     double v[5][64];          // helper -> master, for the master's next step: Q_uu, Q_u, its Cholesky factor L, 1 / L, the warm start
     int st[64];               // ... and BW_OK / BW_NOT_PD / BW_LINALG (the PD test of ilqr_core.py:137-140)
@@ -661,14 +666,14 @@ struct PairX {
     int fix;                  // the guess of the step just verified was wrong in some lane
     double mu[64];            // per sweep, master -> helper
     int act[64], cur[64], gnew[64];
-    int cmd;                  // 1 = run a sweep, 0 = leave
+    int cmd;                  // 1 = run a backward sweep, 2 = run the angle chain of a rollout, 0 = leave
     double dJ[2][64];         // per sweep, verifier -> master (three wavefronts): Delta_J1, Delta_J2 ...
     int cnt[3][64];           // ... and the boxQP counters
     double ja[14][64];        // master -> helper (three wavefronts): the Jacobian of the step after next
     double fw[2][3][64];      // shared rollout (two sets, used in turn): helper -> master sin, cos of the next angle; master -> helper its rate
 };
 
-// LDS hand-over between the two wavefronts of a pair: waits for LDS only, so global loads issued ahead
+// LDS hand-over between the wavefronts of a group: waits for LDS only, so global loads issued ahead
 // of the barrier stay in flight across it.
 __device__ __forceinline__ void pair_barrier()
 {
