@@ -769,3 +769,23 @@ def test_shortest_horizons_and_option_corners_through_every_sweep_variant(hip, m
                   Q_terminal=Mo.Qt + r.uniform(-2, 2, (5, 5)), x_goal=Mo.x_goal, u_goal=[0.3], lower=Mo.lower,
                   upper=Mo.upper)
     _check_solve(hip, Mf, x0, us0, 25)
+
+
+@pytest.mark.parametrize("group", ["3", "2", "1"])
+def test_a_problem_that_searches_past_the_first_step_size_in_most_iterations(hip, monkeypatch, group):
+    """The group of 64 problems of the random 12288-problem batch that holds problem 632: its line search goes past
+    alpha_0 in 191 of its 200 iterations (90 winners at a later step size, re-run with stores; 101 iterations in
+    which every step size fails) and 98 of its backward passes end on a non-PD Q_uu.  Every output and the whole
+    trace against the oracle, through the one-, two- and three-wavefront sweeps."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setenv("ILQR_SOLVE_GROUP", group)
+    x0, us0 = bench.make_batch(12288, 0)
+    sl = slice(576, 640)
+    ref, _ = _check_solve(hip, co.cartpole_model(T=bench.T), x0[sl], us0[sl], 200)
+    it = int(ref["iters"][632 - 576])
+    ai = ref["trace"]["alpha_idx"][632 - 576, :it]
+    assert it == 200 and (ai > 0).sum() > 150 and (ai == 30).sum() > 50
+    assert (ref["trace"]["stopped_at"][632 - 576, :it] >= 0).sum() > 50
