@@ -531,7 +531,10 @@ __global__ __launch_bounds__(WAVE) void k_backward_staged(QPOptsP QOp, BoundsP b
 
 // _forward_pass + _trajectory_cost for one (problem, alpha)   (ilqr_core.py:85-107, :230-239).
 // xs_new / us_new may be null (cost only).
-template <bool STORE, class Cost>
+__device__ __forceinline__ void pair_barrier();
+// SYNC: the wavefront attends one workgroup hand-over per step (it runs beside a rollout that two other wavefronts
+// share, see forward_rollout_master).
+template <bool STORE, class Cost, bool SYNC = false>
 __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost& C, int T,
                                                   int64_t ld, int64_t b,
                                                   const double* __restrict__ xs,
@@ -576,6 +579,8 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost
         C.at(t);
         J = J + C.l(xn, un);
         cartpole_f(P, xn, un, xt);
+        if (SYNC)
+            pair_barrier();
         if (STORE) {
 #pragma unroll
             for (int a = 0; a < NX; ++a)
@@ -670,6 +675,10 @@ struct PairX {
     double dJ[2][64];         // per sweep, verifier -> master (three wavefronts): Delta_J1, Delta_J2 ...
     int cnt[3][64];           // ... and the boxQP counters
     double ja[14][64];        // master -> helper (three wavefronts): the Jacobian of the step after next
+    // three wavefronts: further step sizes tried by the verifier beside the first rollout, for up to SPEC_MAX problems
+    // that went past the first step size in the iteration before
+    int spec_n, spec_col[2], spec_cur[2], spec_gcur[2];
+    double specJ[2][32];
     double fw[2][3][64];      // shared rollout (two sets, used in turn): helper -> master sin, cos of the next angle; master -> helper its rate
 };
 
@@ -1429,7 +1438,10 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                 const bool act = s_pair.act[lane] != 0;
                 const int pc = s_pair.cur[lane], pg = s_pair.gnew[lane];
                 if (cmd == 2) { // the angle chain of the master's rollout
+                    const int sn = GROUP == 3 ? s_pair.spec_n : 0;
                     forward_rollout_helper(P, T, ld, bq, s_pair, lane, XS(pc));
+                    if (sn > 0)
+                        __syncthreads(); // (the verifier's costs reach the master)
                     continue;
                 }
                 pair_helper_sweep<Cost, GROUP == 3>(P, C, T, ld, bq, s_pair, lane, act, XS(pc), US(pc), s_pair.mu[lane],
@@ -1444,9 +1456,25 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                 const int cmd = s_pair.cmd;
                 if (cmd == 0)
                     break;
-                if (cmd == 2) { // a rollout shared by the other two: only their hand-overs to attend
-                    for (int t = 0; t < T; ++t)
-                        pair_barrier();
+                if (cmd == 2) { // a rollout shared by the other two
+                    const int sn = s_pair.spec_n;
+                    if (sn > 0) {
+                        // ... beside which this wavefront tries the further step sizes of the problems that needed
+                        // them in the iteration before (lane = problem and step size), attending the hand-overs
+                        const int n_more = O.n_alpha - 1;
+                        const bool on = lane < sn * n_more;
+                        const int fi = on ? lane / n_more : 0, jj = on ? 1 + lane % n_more : 1;
+                        const int pc = s_pair.spec_cur[fi], pg = s_pair.spec_gcur[fi];
+                        const double Jc = forward_rollout<false, Cost, true>(P, C, T, ld, (int64_t)s_pair.spec_col[fi], XS(pc),
+                                                                             US(pc), KF(pg), KG(pg), s_alpha[jj], nullptr,
+                                                                             nullptr);
+                        if (on)
+                            s_pair.specJ[fi][jj] = Jc;
+                        __syncthreads();
+                    } else { // ... only their hand-overs to attend
+                        for (int t = 0; t < T; ++t)
+                            pair_barrier();
+                    }
                     continue;
                 }
                 const bool act = s_pair.act[lane] != 0;
@@ -1489,6 +1517,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     }
     int converged = 0, status = ILQR_RAN_OUT;
     int iters = 0;
+    bool past_first = false; // the line search of the iteration before went past the first step size
     bool running = valid && O.max_iter > 0;
     const int n_more = O.n_alpha - 1; // candidates after alpha_0
 
@@ -1541,9 +1570,26 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         }
         PP_T(ti1);
         PP_ADD(0, 5, ti0, ti1);
+        int spec_slot = -1, spec_n = 0; // (three wavefronts) this lane's place among the problems the verifier tries ahead
         if constexpr (PAIR) {
             if (O.n_alpha > 0) { // the first rollout is shared with the helper wavefront
                 s_pair.cur[lane] = cur;
+                if constexpr (GROUP == 3) {
+                    const bool want_spec = past_first && running && n_more > 0 && n_more * 2 <= 64;
+                    const unsigned long long pm = __ballot(want_spec);
+                    if (pm != 0ull) {
+                        const int r = __popcll(pm & ((1ull << lane) - 1ull));
+                        if (want_spec && r < 2) {
+                            spec_slot = r;
+                            s_pair.spec_col[r] = (int)b;
+                            s_pair.spec_cur[r] = cur;
+                            s_pair.spec_gcur[r] = gcur;
+                        }
+                        spec_n = __popcll(pm) < 2 ? __popcll(pm) : 2;
+                    }
+                    if (lane == 0)
+                        s_pair.spec_n = spec_n;
+                }
                 if (lane == 0)
                     s_pair.cmd = 2;
                 __syncthreads();
@@ -1592,11 +1638,38 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         }
         PP_T(ti2);
         PP_ADD(0, 6, ti1, ti2);
+        bool redo = false; // accepted at some alpha_j, j >= 1: its trajectory still has to be written
+        // the reference's loop from alpha_1 on, on tabulated costs
+        auto scan_costs = [&](const double* row) {
+            for (j = 1; j < O.n_alpha; ++j) {
+                double alpha = s_alpha[j];
+                Jnew = row[j];
+                double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+                if (expected <= 0.0) {
+                    break;
+                } else if ((J - Jnew) / expected > O.scale) {
+                    actual = J - Jnew;
+                    accepted = 1;
+                    redo = true;
+                    break;
+                }
+            }
+            need = false;
+        };
+        past_first = need;
+        if constexpr (GROUP == 3) {
+            if (spec_n > 0) { // the verifier has tried the further step sizes of up to two problems already
+                __syncthreads();
+                if (need && spec_slot >= 0)
+                    scan_costs(s_pair.specJ[spec_slot]);
+                if (lane == 0)
+                    s_pair.spec_n = 0; // (a re-run below is a shared rollout without this)
+            }
+        }
         // ---- remaining alphas of the problems that need them, LS_PASS problems per pass
         // (helper lanes read gains another lane of this wave has just stored)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         unsigned long long mask = __ballot(need);
-        bool redo = false; // accepted at some alpha_j, j >= 1: its trajectory still has to be written
         while (mask != 0ull) {
             int rank = __popcll(mask & ((1ull << lane) - 1ull));
             bool mine = need && rank < LS_PASS;
@@ -1620,23 +1693,8 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (mine) {
-                // the reference's loop from alpha_1 on, on the tabulated costs
-                for (j = 1; j < O.n_alpha; ++j) {
-                    double alpha = s_alpha[j];
-                    Jnew = s_J[wv][rank][j];
-                    double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
-                    if (expected <= 0.0) {
-                        break;
-                    } else if ((J - Jnew) / expected > O.scale) {
-                        actual = J - Jnew;
-                        accepted = 1;
-                        redo = true;
-                        break;
-                    }
-                }
-                need = false;
-            }
+            if (mine)
+                scan_costs(s_J[wv][rank]);
             __builtin_amdgcn_wave_barrier();
             mask = __ballot(need);
         }
