@@ -399,9 +399,10 @@ def test_plant_step_bit_exact(hip):
     assert eq(hip.plant_step(dev(st), dev(u)).cpu().numpy(), co.plant_step(st, u))
 
 
-def test_full_size_batch_properties(hip):
-    """C1 at its full size (16384 problems): properties that need no oracle run."""
-    B = 16384
+@pytest.mark.parametrize("B", [16384, 20480, 32768, 40000])
+def test_full_size_batch_properties(hip, B):
+    """C1 at its full size (16384 problems: three wavefronts per group of 64) and at the sizes that take the other
+    launch shapes (two wavefronts per group up to 32768, one beyond): properties that need no oracle run."""
     x0, us0 = co.cartpole_batch(B)
     Mo = co.cartpole_model()
     M = hip_model(hip, Mo)
