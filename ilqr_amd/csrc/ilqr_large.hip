@@ -164,57 +164,112 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// ------------------------------------------------------------------ boxQP in registers
+// ------------------------------------------------------------------ boxQP of one wavefront
 //
-// boxQP (ilqr_boxQP.py:9-186) for m = 8: every lane of the wave runs the same scalar program
-// (uniform control flow), with the 8-vectors and the 8 x 8 factor in registers and every loop
-// unrolled over the full index range; H is read from LDS (broadcast reads).  The reference compacts the free
-// variables before factorising and solving (ilqr_boxQP.py:114-132); here clamped rows and
-// columns of the factor are kept as exact zeros instead: fma(-0, 0, s) == s and b[j] == 0
-// for a clamped j, so every chain over the free indices has the same terms in the same
-// order and gives the same bits as the compacted computation.
+// boxQP (ilqr_boxQP.py:9-186) for m = 8, one problem per wavefront.  The parts of a pass that are sums over
+// the variables -- H x (the gradient, :82), H_fc x_c (:126-129), the objective (:62, :148), the norm of the
+// free gradient (:120), the slope of the Armijo test (:147) -- are fp64 MFMA chains over two k-blocks
+// (v_mfma_f64_16x16x4_f64 is the k-ascending chain fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C))))):
+// the same terms in the same order as the scalar "first product, then fma" chains, so the same bits.  An
+// 8-vector lives in V layout (V8: lane group g holds elements g and g + 4, replicated over the 16 columns),
+// the 8 x 8 matrix as two registers of its N-layout tile, and the Armijo loop evaluates 16 consecutive trips
+// as the 16 columns of an 8 x 16 candidate matrix.  What is inherently serial -- the Cholesky factor and the
+// two triangular solves -- stays one scalar program that every lane runs on wave-uniform values.
+// The reference compacts the free variables before factorising and solving (ilqr_boxQP.py:114-132); here
+// clamped entries are kept as exact zeros instead: fma(a, 0, s) == s for finite a, so every chain over the
+// free (or the clamped) indices has the same terms in the same order and gives the same bits as the compacted
+// computation (only the sign of an exact zero can differ).
+struct V8 {
+    double a, b; // elements g and g + 4
+};
+
+__device__ __forceinline__ double rl64(double v, int lane) // v of `lane` (wave-uniform index) on every lane
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// element I of a V8 as a wave-uniform value
+template <int I>
+__device__ __forceinline__ double v8_uni(const V8& v)
+{
+    return rl64(I < 4 ? v.a : v.b, 16 * (I & 3));
+}
+// V8 of a wave-uniform 8-vector
+__device__ __forceinline__ V8 v8_of(const double (&u)[LM], int g)
+{
+    V8 v;
+    v.a = g == 0 ? u[0] : (g == 1 ? u[1] : (g == 2 ? u[2] : u[3]));
+    v.b = g == 0 ? u[4] : (g == 1 ? u[5] : (g == 2 ? u[6] : u[7]));
+    return v;
+}
+__device__ __forceinline__ V8 v8_load(const double* p, int g) { return V8{p[g], p[g + 4]}; }
+
+// sum over k = 0..7 of X[k][i] Y[k][j] as one chain (two k-blocks): X, Y given by their two registers
+__device__ __forceinline__ d4 mf2(double xa, double xb, double ya, double yb)
+{
+    d4 acc = zero4();
+    acc = mfma4(xa, ya, acc);
+    acc = mfma4(xb, yb, acc);
+    return acc;
+}
+// a[0] b[0], then fma(a[i], b[i], .) for i = 1..7: every lane gets the sum
+__device__ __forceinline__ double v8_dot(const V8& a, const V8& b) { return mf2(a.a, a.b, b.a, b.b)[0]; }
+
+struct H8 {   // Q_uu
+    V8 n, t;  // N-layout tiles of H and of H^T (n.a = H[g][c], n.b = H[g+4][c], t.a = H[c][g], t.b = H[c][g+4]; 0 for c >= 8)
+    double e; // entry e of the row-major matrix on lane e (for the scalar factorisation: an entry is a lane read)
+    __device__ __forceinline__ double operator[](int i) const { return rl64(e, i); }
+};
+__device__ __forceinline__ H8 h8_load(const double* Hm, LaneId L, int lane) // Hm: row-major 8 x 8 in LDS
+{
+    H8 H;
+    const bool in = L.c < LM;
+    const int c = in ? L.c : 0;
+    H.n.a = in ? Hm[L.g * LM + c] : 0.0;
+    H.n.b = in ? Hm[(L.g + 4) * LM + c] : 0.0;
+    H.t.a = in ? Hm[c * LM + L.g] : 0.0;
+    H.t.b = in ? Hm[c * LM + L.g + 4] : 0.0;
+    H.e = Hm[lane];
+    return H;
+}
+// H x (rows of H times x), V layout
+__device__ __forceinline__ V8 h8_mul(const H8& H, const V8& x)
+{
+    d4 y = mf2(H.t.a, H.t.b, x.a, x.b);
+    return V8{y[0], y[1]};
+}
+// x^T H (x times the columns of H), V layout
+__device__ __forceinline__ V8 h8_tmul(const H8& H, const V8& x)
+{
+    d4 y = mf2(H.n.a, H.n.b, x.a, x.b);
+    return V8{y[0], y[1]};
+}
+// x.g + 0.5 x^T H x as the reference forms it (ilqr_boxQP.py:62)
+__device__ __forceinline__ double h8_value(const H8& H, const V8& g, const V8& x)
+{
+    double xg = v8_dot(x, g);
+    double tot = v8_dot(h8_tmul(H, x), x);
+    return xg + 0.5 * tot;
+}
+
 struct QPR {
-    double x[LM];
+    V8 x;                      // in: warm start, out: solution
     const double *g, *lo, *hi; // LDS
     double Lf[LM][LM];         // masked lower factor of H_ff (all ones until the first factorisation, :36)
     double rd[LM];             // 1 / Lf[i][i], formed once per factorisation (the bits every solve would form)
     unsigned fmask;            // free set Lf was computed for (bit i = variable i free)
     bool factored;             // false: boxQP has not factorised yet, H_ff is still the all-ones matrix of :36
-    bool fr[LM];       // free mask of the last classification
+    unsigned frm;              // free set of the last classification (wave-uniform)
     int result, n_iter, n_factor, n_bt, nf;
     bool linalg;
 };
 
-// Q_uu (8 x 8) of the wave's problem with entry e held by lane e: one register for the whole matrix, and an
-// entry is a lane read (two scalar moves) instead of an LDS load whose latency every dependent chain of the
-// boxQP would wait for.
-struct HLanes {
-    double v;
-    __device__ __forceinline__ double operator[](int e) const
-    {
-        int lo = __builtin_amdgcn_readlane(__double2loint(v), e);
-        int hi = __builtin_amdgcn_readlane(__double2hiint(v), e);
-        return __hiloint2double(hi, lo);
-    }
-};
-
-// The free set as a scalar bit mask: every lane of the wave holds the same problem, so the mask is
-// wave-uniform and a test of one of its bits is a scalar branch (clamped rows and columns are then
-// skipped instead of computed and discarded; what is skipped are exact zeros and the unused pivots).
-__device__ __forceinline__ unsigned lr_mask(const bool (&fr)[LM])
-{
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < LM; ++i)
-        m |= fr[i] ? (1u << i) : 0u;
-    return __builtin_amdgcn_readfirstlane(m);
-}
-
-// Lower Cholesky factor of H restricted to the free set; returns true if a free pivot is not > 0.
+// Lower Cholesky factor of H restricted to the free set fm (wave-uniform: clamped rows and columns are
+// skipped by scalar branches); returns true if a free pivot is not > 0.
 template <class HT>
-__device__ __forceinline__ bool lr_chol(const HT& H, const bool (&fr)[LM], double (&Lf)[LM][LM], double (&rd)[LM])
+__device__ __forceinline__ bool lr_chol(const HT& H, unsigned fm, double (&Lf)[LM][LM], double (&rd)[LM])
 {
-    const unsigned fm = lr_mask(fr);
     bool fail = false;
 #pragma unroll
     for (int j = 0; j < LM; ++j) {
@@ -241,14 +296,14 @@ __device__ __forceinline__ bool lr_chol(const HT& H, const bool (&fr)[LM], doubl
 #pragma unroll
             for (int k = 0; k < j; ++k)
                 t = fma(-Lf[i][k], Lf[j][k], t);
-            Lf[i][j] = fr[i] ? t * r : 0.0;
+            Lf[i][j] = (fm & (1u << i)) ? t * r : 0.0;
         }
     }
     return fail;
 }
 
 // cho_solve on the free set, b = 0 on clamped entries on exit
-__device__ __forceinline__ void lr_solve(const double (&Lf)[LM][LM], const double (&rd)[LM], const bool (&fr)[LM],
+__device__ __forceinline__ void lr_solve(const double (&Lf)[LM][LM], const double (&rd)[LM], unsigned fm,
                                          double (&b)[LM])
 {
 #pragma unroll
@@ -257,7 +312,7 @@ __device__ __forceinline__ void lr_solve(const double (&Lf)[LM][LM], const doubl
 #pragma unroll
         for (int j = 0; j < i; ++j)
             s = fma(-Lf[i][j], b[j], s);
-        b[i] = fr[i] ? s * rd[i] : 0.0;
+        b[i] = (fm & (1u << i)) ? s * rd[i] : 0.0;
     }
 #pragma unroll
     for (int i = LM - 1; i >= 0; --i) {
@@ -265,7 +320,7 @@ __device__ __forceinline__ void lr_solve(const double (&Lf)[LM][LM], const doubl
 #pragma unroll
         for (int j = i + 1; j < LM; ++j)
             s = fma(-Lf[j][i], b[j], s);
-        b[i] = fr[i] ? s * rd[i] : 0.0;
+        b[i] = (fm & (1u << i)) ? s * rd[i] : 0.0;
     }
 }
 
@@ -291,6 +346,7 @@ __device__ __forceinline__ void lr_solve_ones(double (&b)[LM])
     }
 }
 
+// the scalar objective on wave-uniform or per-lane vectors (used by the 64-trip rounds of the Armijo loop)
 template <class HT>
 __device__ __forceinline__ double lr_value(const HT& H, const double* g, const double (&x)[LM])
 {
@@ -310,12 +366,6 @@ __device__ __forceinline__ double lr_value(const HT& H, const double* g, const d
     return xg + 0.5 * tot;
 }
 
-// H: Q_uu, finite and positive definite (the caller has checked), entry e on lane e (HLanes; a copy of all 64
-// entries in registers was measured: what the boxQP gains, the matrix part loses to spills; read from LDS entry by
-// entry the solve of 8192 problems takes 705 instead of 669 ms); steps: the wave's step table.
-// On entry Q.x holds the warm start and Q.Lf / Q.rd / Q.fmask the factor of the full H (the caller
-// needed it for the warm start): a factorisation for a free set that Lf already belongs to is not
-// repeated (same inputs, same bits); the reference's counter still counts it.
 #ifdef ILQR_LARGE_QP_PROF // diagnostic build only: shader clocks per part of a boxQP pass, summed over waves
 static __device__ unsigned long long g_lqp[8];
 #define LQP_T(var) long long var = clock64()
@@ -325,23 +375,39 @@ static __device__ unsigned long long g_lqp[8];
 #define LQP_ADD(slot, a, b)
 #endif
 
-template <class HT>
-__device__ void lr_boxqp(const LQPOpts& O, const HT& H, const double* steps, QPR& Q)
+// bit i of the result = variable i, from the ballots of a per-lane flag on the two registers of a V8
+__device__ __forceinline__ unsigned v8_mask(bool fa, bool fb)
+{
+    unsigned long long ba = __ballot(fa), bb = __ballot(fb);
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        m |= (unsigned)((ba >> (16 * q)) & 1ull) << q;
+        m |= (unsigned)((bb >> (16 * q)) & 1ull) << (q + 4);
+    }
+    return m;
+}
+
+// H: Q_uu, finite and positive definite (the caller has checked); steps: the wave's step table.
+// On entry Q.x holds the warm start and Q.Lf / Q.rd / Q.fmask the factor of the full H (the caller
+// needed it for the warm start): a factorisation for a free set that Lf already belongs to is not
+// repeated (same inputs, same bits); the reference's counter still counts it.
+__device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR& Q)
 {
 #ifdef ILQR_LARGE_QP_PROF
     unsigned long long lqp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    bool cl[LM];
-#pragma unroll
-    for (int i = 0; i < LM; ++i) {
-        cl[i] = false;
-        Q.fr[i] = false;
-        Q.x[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i]);
-    }
+    const LaneId L = lane_id();
+    const int ln = threadIdx.x & 63;
+    const V8 gV = v8_load(Q.g, L.g), loV = v8_load(Q.lo, L.g), hiV = v8_load(Q.hi, L.g);
+    V8 x{lclamp(loV.a, hiV.a, Q.x.a), lclamp(loV.b, hiV.b, Q.x.b)};
+    unsigned clm = 0; // clamped set of the last classification
+    Q.frm = 0;
     Q.factored = false;
-    double value = lr_value(H, Q.g, Q.x), oldvalue = 0.0;
+    double value = h8_value(H, gV, x), oldvalue = 0.0;
     int result = -1, n_iter = 0, n_factor = 0, n_bt = 0;
     bool linalg = false;
+    const bool tabulated = O.n_exhaust < LQ_TAB;
     for (int iter = 0; iter < O.max_iter; ++iter) {
         if (result != -1)
             break;
@@ -351,22 +417,16 @@ __device__ void lr_boxqp(const LQPOpts& O, const HT& H, const double* steps, QPR
         }
         oldvalue = value;
         LQP_T(q0);
-        double grad[LM];
-        bool changed = false;
-        int nclamped = 0;
-#pragma unroll
-        for (int i = 0; i < LM; ++i) {
-            double acc = H[i * LM] * Q.x[0];
-#pragma unroll
-            for (int j = 1; j < LM; ++j)
-                acc = fma(H[i * LM + j], Q.x[j], acc);
-            grad[i] = Q.g[i] + acc;
-            bool c = ((Q.x[i] == Q.lo[i]) && (grad[i] > 0.0)) || ((Q.x[i] == Q.hi[i]) && (grad[i] < 0.0));
-            changed = changed || (c != cl[i]);
-            cl[i] = c;
-            Q.fr[i] = !c;
-            nclamped += c ? 1 : 0;
-        }
+        // grad = g + H x ; clamped = (x == lower & grad > 0) | (x == upper & grad < 0)   (:82-89)
+        const V8 hx = h8_mul(H, x);
+        const V8 grad{gV.a + hx.a, gV.b + hx.b};
+        const bool ca = ((x.a == loV.a) && (grad.a > 0.0)) || ((x.a == hiV.a) && (grad.a < 0.0));
+        const bool cb = ((x.b == loV.b) && (grad.b > 0.0)) || ((x.b == hiV.b) && (grad.b < 0.0));
+        const unsigned ncl = v8_mask(ca, cb);
+        const bool changed = ncl != clm;
+        clm = ncl;
+        Q.frm = ~clm & 0xffu;
+        const int nclamped = __builtin_popcount(clm);
         if (nclamped == LM) {
             result = 6;
             break;
@@ -374,16 +434,12 @@ __device__ void lr_boxqp(const LQPOpts& O, const HT& H, const double* steps, QPR
         LQP_T(q1);
         LQP_ADD(0, q0, q1);
         if (iter == 1 || changed) {
-            unsigned mask = 0;
-#pragma unroll
-            for (int i = 0; i < LM; ++i)
-                mask |= Q.fr[i] ? (1u << i) : 0u;
-            if (mask != Q.fmask) {
-                if (lr_chol(H, Q.fr, Q.Lf, Q.rd)) {
+            if (Q.frm != Q.fmask) {
+                if (lr_chol(H, Q.frm, Q.Lf, Q.rd)) {
                     linalg = true; // sla.cholesky raises LinAlgError
                     break;
                 }
-                Q.fmask = mask;
+                Q.fmask = Q.frm;
             }
             Q.factored = true;
             ++n_factor;
@@ -391,16 +447,14 @@ __device__ void lr_boxqp(const LQPOpts& O, const HT& H, const double* steps, QPR
         LQP_T(q2);
         LQP_ADD(1, q1, q2);
         // sla.norm(grad[free]); dnrm2 of a single element is its magnitude
-        double ss = 0.0, g1 = 0.0;
-        bool first = true;
-#pragma unroll
-        for (int i = 0; i < LM; ++i) {
-            double sq = first ? grad[i] * grad[i] : fma(grad[i], grad[i], ss);
-            g1 = (Q.fr[i] && first) ? grad[i] : g1;
-            ss = Q.fr[i] ? sq : ss;
-            first = first && !Q.fr[i];
+        const V8 gm{ca ? 0.0 : grad.a, cb ? 0.0 : grad.b};
+        double gnorm;
+        if (LM - nclamped == 1) {
+            const V8 one{ca ? 0.0 : 1.0, cb ? 0.0 : 1.0};
+            gnorm = fabs(v8_dot(gm, one));
+        } else {
+            gnorm = sqrt(v8_dot(gm, gm));
         }
-        double gnorm = (LM - nclamped) == 1 ? fabs(g1) : sqrt(ss);
         if (gnorm < O.min_grad) {
             result = 5;
             break;
@@ -408,110 +462,124 @@ __device__ void lr_boxqp(const LQPOpts& O, const HT& H, const double* steps, QPR
         ++n_iter;
         LQP_T(q3);
         LQP_ADD(2, q2, q3);
-        // grad_clamped = g[free] + H_fc x[clamped]; search[free] = -cho_solve(H_ff, .) - x[free]
-        // (every lane of the wave holds the same problem: the clamped set is wave-uniform, and as
-        // a scalar bit mask it lets the chain skip the unclamped columns instead of computing and
-        // discarding their terms)
-        double rhs[LM], search[LM];
+        // grad_clamped = g[free] + H_fc x[clamped]; search[free] = -cho_solve(H_ff, .) - x[free]   (:126-132)
+        V8 search;
         {
-            unsigned clm = 0;
-#pragma unroll
-            for (int j = 0; j < LM; ++j)
-                clm |= cl[j] ? (1u << j) : 0u;
-            clm = __builtin_amdgcn_readfirstlane(clm);
-            double acc[LM];
-#pragma unroll
-            for (int i = 0; i < LM; ++i)
-                acc[i] = 0.0;
-            bool f1 = true;
-#pragma unroll
-            for (int j = 0; j < LM; ++j) {
-                if (clm & (1u << j)) {
-                    if (f1) {
-#pragma unroll
-                        for (int i = 0; i < LM; ++i)
-                            acc[i] = H[i * LM + j] * Q.x[j];
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < LM; ++i)
-                            acc[i] = fma(H[i * LM + j], Q.x[j], acc[i]);
-                    }
-                    f1 = false;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < LM; ++i)
-                rhs[i] = Q.fr[i] ? Q.g[i] + acc[i] : 0.0;
+            const V8 xcl{ca ? x.a : 0.0, cb ? x.b : 0.0};
+            const V8 hc = h8_mul(H, xcl);
+            const V8 rv{ca ? 0.0 : gV.a + hc.a, cb ? 0.0 : gV.b + hc.b};
+            LQP_T(q4);
+            LQP_ADD(3, q3, q4);
+            double rhs[LM] = {v8_uni<0>(rv), v8_uni<1>(rv), v8_uni<2>(rv), v8_uni<3>(rv),
+                              v8_uni<4>(rv), v8_uni<5>(rv), v8_uni<6>(rv), v8_uni<7>(rv)};
+            if (Q.factored)
+                lr_solve(Q.Lf, Q.rd, Q.frm, rhs);
+            else
+                lr_solve_ones(rhs);
+            const V8 sol = v8_of(rhs, L.g);
+            search.a = ca ? 0.0 : sol.a * -1 - x.a;
+            search.b = cb ? 0.0 : sol.b * -1 - x.b;
+            LQP_T(q5);
+            LQP_ADD(4, q4, q5);
         }
-        LQP_T(q4);
-        LQP_ADD(3, q3, q4);
-        if (Q.factored)
-            lr_solve(Q.Lf, Q.rd, Q.fr, rhs);
-        else
-            lr_solve_ones(rhs);
-#pragma unroll
-        for (int i = 0; i < LM; ++i)
-            search[i] = Q.fr[i] ? rhs[i] * -1 - Q.x[i] : 0.0;
-        LQP_T(q5);
-        LQP_ADD(4, q4, q5);
+        LQP_T(q5b);
 
-        // Armijo line search (:140-159).  The candidates of the reference's backtracking loop do
-        // not depend on each other, so the wave evaluates 64 consecutive trips at once (lane =
-        // trip, each lane runs the reference's scalar arithmetic for its own step) and takes the
-        // first trip at which the loop would have ended: the test fails, or the step has dropped
-        // below min_step (result 2).
-        const int ln = threadIdx.x & 63;
-        double step = 1.0; // only used by the serial fallback
-        for (int tb = 0;; tb += 64) {
-            int t = tb + ln;
-            bool tabulated = O.n_exhaust < LQ_TAB;
-            bool in_range = tabulated ? t <= O.n_exhaust : ln == 0;
-            double st = tabulated ? steps[in_range ? t : 0] : step;
-            double xc[LM];
+        // Armijo line search (:140-159).  The candidates of the reference's backtracking loop do not depend
+        // on each other.  Trips 0..15 are evaluated as the 16 columns of an 8 x 16 candidate matrix (lane
+        // (g, c) forms variables g and g + 4 of trip c); the trip of column c has its objective and slope on
+        // the lane with g == c & 3.  The first trip at which the loop would have ended -- the test fails, or
+        // the step has dropped below min_step (result 2) -- wins.
+        bool found = false;
+        if (tabulated) {
+            const int t = L.c;
+            const bool in_range = t <= O.n_exhaust;
+            const double st = steps[in_range ? t : 0];
+            const V8 xc{lclamp(loV.a, hiV.a, x.a + st * search.a), lclamp(loV.b, hiV.b, x.b + st * search.b)};
+            const double pa = (xc.a - x.a) * grad.a, pb = (xc.b - x.b) * grad.b;
+            const d4 sd = mf2(pa, pb, 1.0, 1.0);              // row t: sum of the slope terms, in order
+            const d4 xg = mf2(xc.a, xc.b, gV.a, gV.b);        // row t: x_c . g
+            const d4 ac = mf2(H.n.a, H.n.b, xc.a, xc.b);      // [j][t]: x_c^T H
+            const d4 tt = mf2(ac[0], ac[1], xc.a, xc.b);      // [t][t]: (x_c^T H) x_c
+            const int rs = L.c >> 2;
+            const double tot_t = rs == 0 ? tt[0] : (rs == 1 ? tt[1] : (rs == 2 ? tt[2] : tt[3]));
+            const double sd_t = rs == 0 ? sd[0] : (rs == 1 ? sd[1] : (rs == 2 ? sd[2] : sd[3]));
+            const double xg_t = rs == 0 ? xg[0] : (rs == 1 ? xg[1] : (rs == 2 ? xg[2] : xg[3]));
+            const double vc = xg_t + 0.5 * tot_t;
+            const bool cont = (vc - oldvalue) / (sd_t + 1e-10) < O.armijo;
+            const bool stop = (L.g == (L.c & 3)) && in_range && (!cont || t == O.n_exhaust);
+            const unsigned long long m = __ballot(stop);
+            const unsigned m16 = (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
+            if (m16 != 0u) {
+                const int cs = __ffs((int)m16) - 1;
+                n_bt += cs;
+                if (cs == O.n_exhaust)
+                    result = 2;
+                x.a = __shfl(xc.a, (ln & 48) | cs);
+                x.b = __shfl(xc.b, (ln & 48) | cs);
+                value = rl64(vc, 16 * (cs & 3) + cs);
+                found = true;
+            }
+        }
+        if (!found) {
+            // the trips from 16 on (or all of them, one per round on lane 0, when the step table is too short
+            // for the options): 64 at a time, lane = trip, each lane runs the reference's scalar arithmetic
+            double xu[LM] = {v8_uni<0>(x), v8_uni<1>(x), v8_uni<2>(x), v8_uni<3>(x),
+                             v8_uni<4>(x), v8_uni<5>(x), v8_uni<6>(x), v8_uni<7>(x)};
+            const double gu[LM] = {v8_uni<0>(grad), v8_uni<1>(grad), v8_uni<2>(grad), v8_uni<3>(grad),
+                                   v8_uni<4>(grad), v8_uni<5>(grad), v8_uni<6>(grad), v8_uni<7>(grad)};
+            const double su[LM] = {v8_uni<0>(search), v8_uni<1>(search), v8_uni<2>(search), v8_uni<3>(search),
+                                   v8_uni<4>(search), v8_uni<5>(search), v8_uni<6>(search), v8_uni<7>(search)};
+            double step = 1.0; // only used without the table
+            for (int tb = tabulated ? 16 : 0;; tb += 64) {
+                int t = tb + ln;
+                bool in_range = tabulated ? t <= O.n_exhaust : ln == 0;
+                double st = tabulated ? steps[in_range ? t : 0] : step;
+                double xc[LM];
 #pragma unroll
-            for (int i = 0; i < LM; ++i)
-                xc[i] = lclamp(Q.lo[i], Q.hi[i], Q.x[i] + st * search[i]);
-            double sdotg = (xc[0] - Q.x[0]) * grad[0];
+                for (int i = 0; i < LM; ++i)
+                    xc[i] = lclamp(Q.lo[i], Q.hi[i], xu[i] + st * su[i]);
+                double sdotg = (xc[0] - xu[0]) * gu[0];
 #pragma unroll
-            for (int i = 1; i < LM; ++i)
-                sdotg = sdotg + (xc[i] - Q.x[i]) * grad[i];
-            double vc = lr_value(H, Q.g, xc);
-            bool cont = (vc - oldvalue) / (sdotg + 1e-10) < O.armijo;
-            if (!tabulated) {
-                // one trip per pass on lane 0 (step tables longer than LQ_TAB are not kept)
-                int trip = tb / 64;
-                bool small = trip > 0 && st < O.min_step;
-                unsigned long long stopm = __ballot(ln == 0 && (!cont || small));
-                if (stopm != 0ull) {
-                    n_bt += trip;
-                    if (small)
+                for (int i = 1; i < LM; ++i)
+                    sdotg = sdotg + (xc[i] - xu[i]) * gu[i];
+                double vc = lr_value(H, Q.g, xc);
+                bool cont = (vc - oldvalue) / (sdotg + 1e-10) < O.armijo;
+                if (!tabulated) {
+                    int trip = tb / 64;
+                    bool small = trip > 0 && st < O.min_step;
+                    unsigned long long stopm = __ballot(ln == 0 && (!cont || small));
+                    if (stopm != 0ull) {
+                        n_bt += trip;
+                        if (small)
+                            result = 2;
+#pragma unroll
+                        for (int i = 0; i < LM; ++i)
+                            xu[i] = rl64(xc[i], 0);
+                        value = rl64(vc, 0);
+                        break;
+                    }
+                    step = step * O.step_dec;
+                    continue;
+                }
+                bool stop = in_range && (!cont || t == O.n_exhaust);
+                unsigned long long mask = __ballot(stop);
+                if (mask != 0ull) {
+                    int w = __ffsll((long long)mask) - 1;
+                    int tstar = tb + w;
+                    n_bt += tstar;
+                    if (tstar == O.n_exhaust)
                         result = 2;
 #pragma unroll
                     for (int i = 0; i < LM; ++i)
-                        Q.x[i] = __shfl(xc[i], 0);
-                    value = __shfl(vc, 0);
+                        xu[i] = rl64(xc[i], w);
+                    value = rl64(vc, w);
                     break;
                 }
-                step = step * O.step_dec;
-                continue;
             }
-            bool stop = in_range && (!cont || t == O.n_exhaust);
-            unsigned long long mask = __ballot(stop);
-            if (mask != 0ull) {
-                int w = __ffsll((long long)mask) - 1;
-                int tstar = tb + w;
-                n_bt += tstar;
-                if (tstar == O.n_exhaust)
-                    result = 2;
-#pragma unroll
-                for (int i = 0; i < LM; ++i)
-                    Q.x[i] = __shfl(xc[i], w);
-                value = __shfl(vc, w);
-                break;
-            }
+            x = v8_of(xu, L.g);
         }
         LQP_T(q6);
-        LQP_ADD(5, q5, q6);
+        LQP_ADD(5, q5b, q6);
 #ifdef ILQR_LARGE_QP_PROF
         lqp_acc[6] += 1;
 #endif
@@ -522,15 +590,12 @@ __device__ void lr_boxqp(const LQPOpts& O, const HT& H, const double* steps, QPR
         for (int q = 0; q < 8; ++q)
             atomicAdd(&g_lqp[q], lqp_acc[q]);
 #endif
-    int nf = 0;
-#pragma unroll
-    for (int i = 0; i < LM; ++i)
-        nf += Q.fr[i] ? 1 : 0;
+    Q.x = x;
     Q.result = result;
     Q.n_iter = n_iter;
     Q.n_factor = n_factor;
     Q.n_bt = n_bt;
-    Q.nf = nf;
+    Q.nf = __builtin_popcount(Q.frm);
     Q.linalg = linalg;
 }
 
@@ -749,8 +814,8 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         }
         long long t_b = prof ? clock64() : 0;
         // np.all(np.linalg.eigvals(Q_uu) > 0) else print / warn / break   (:137-140)
-        const HLanes Hq{S.H[lane & 63]};
-        const bool finite = __ballot(!(fabs(Hq.v) < __builtin_inf())) == 0ull;
+        const H8 Hq = h8_load(S.H, L, lane);
+        const bool finite = __ballot(!(fabs(Hq.e) < __builtin_inf())) == 0ull;
         if (!finite) {
             out.rc = 2;
             break;
@@ -760,19 +825,17 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         qr.lo = S.lo;
         qr.hi = S.hi;
         {
-            bool all_free[LM];
-#pragma unroll
-            for (int a = 0; a < LM; ++a)
-                all_free[a] = true;
-            if (lr_chol(Hq, all_free, qr.Lf, qr.rd)) {
+            if (lr_chol(Hq, 0xffu, qr.Lf, qr.rd)) {
                 out.stopped_at = i;
                 break;
             }
             // k[i] = cho_solve((R_Q_uu, True), Q_u): the (positive-sign) boxQP warm start   (:145)
+            double ws[LM];
 #pragma unroll
             for (int a = 0; a < LM; ++a)
-                qr.x[a] = S.g[a];
-            lr_solve(qr.Lf, qr.rd, all_free, qr.x);
+                ws[a] = S.g[a];
+            lr_solve(qr.Lf, qr.rd, 0xffu, ws);
+            qr.x = v8_of(ws, L.g);
             qr.fmask = 0xffu;
         }
         long long t_b1 = prof ? clock64() : 0;
@@ -790,28 +853,35 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         if (free_mask && lane == 0) {
 #pragma unroll
             for (int a = 0; a < LM; ++a)
-                free_mask[(size_t)i * LM + a] = qr.fr[a] ? 1 : 0;
+                free_mask[(size_t)i * LM + a] = (qr.frm >> a) & 1u;
+        }
+        // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)                 (:175-176)
+        {
+            const V8 gv = v8_load(S.g, L.g);
+            const double d1 = v8_dot(qr.x, gv);
+            const double d2 = v8_dot(qr.x, h8_mul(Hq, qr.x));
+            out.dJ1 = out.dJ1 + d1;
+            out.dJ2 = out.dJ2 + d2 * 0.5;
         }
         // K[i, free, :] = -cho_solve((H_ff, True), Q_ux[free, :]); clamped rows stay 0   (:157-160)
         if (lane < LN) {
             double col[LM];
 #pragma unroll
             for (int a = 0; a < LM; ++a)
-                col[a] = qr.fr[a] ? S.Qux[a][lane] : 0.0;
+                col[a] = (qr.frm & (1u << a)) ? S.Qux[a][lane] : 0.0;
             if (qr.nf > 0) {
                 if (qr.factored)
-                    lr_solve(qr.Lf, qr.rd, qr.fr, col);
+                    lr_solve(qr.Lf, qr.rd, qr.frm, col);
                 else
                     lr_solve_ones(col);
             }
 #pragma unroll
             for (int a = 0; a < LM; ++a)
-                S.K[a][lane] = qr.fr[a] ? col[a] * -1 : 0.0;
+                S.K[a][lane] = (qr.frm & (1u << a)) ? col[a] * -1 : 0.0;
         }
-        if (lane == 0) {
-#pragma unroll
-            for (int a = 0; a < LM; ++a)
-                S.x[a] = qr.x[a];
+        if (L.c == 0) {
+            S.x[L.g] = qr.x.a;
+            S.x[L.g + 4] = qr.x.b;
         }
         wave_sync();
         long long t_c = prof ? clock64() : 0;
@@ -889,25 +959,6 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
                     d4 vt = load_nt(&S.Vn[0][0], LN + 1, LN, LN, rt, ct, L);
                     Vxx[rt][ct] = 0.5 * (Vxx[rt][ct] + vt);
                 }
-        }
-        // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)                 (:175-176)
-        {
-            const double* kq = S.x;
-            double d1 = kq[0] * S.g[0];
-#pragma unroll
-            for (int c = 1; c < LM; ++c)
-                d1 = fma(kq[c], S.g[c], d1);
-            double d2 = 0.0;
-#pragma unroll
-            for (int a = 0; a < LM; ++a) {
-                double acc = Hq[a * LM] * kq[0];
-#pragma unroll
-                for (int c = 1; c < LM; ++c)
-                    acc = fma(Hq[a * LM + c], kq[c], acc);
-                d2 = (a == 0) ? kq[0] * acc : fma(kq[a], acc, d2);
-            }
-            out.dJ1 = out.dJ1 + d1;
-            out.dJ2 = out.dJ2 + d2 * 0.5;
         }
         wave_sync(); // the LDS images are rewritten by the next step
         if (prof) {
