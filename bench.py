@@ -14,11 +14,18 @@ Problems are independent, so there is no collective inside the solve; with N > 1
 the gather of costs, iteration counts and trajectories on rank 0 (RCCL over xGMI), overlapped with the
 next step's solve.
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches itself: the parent (which never
+touches a GPU) starts N child processes, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT set, relays rank 0's JSON line and exits non-zero if any child does.  Under an external launcher
+(torch.distributed.run sets WORLD_SIZE) it runs as one rank of that job.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -88,6 +95,58 @@ def cpu_baseline(n_problems, threads):
                 reference_as_written=REFERENCE_AS_WRITTEN)
 
 
+def self_launch(n_ranks, argv):
+    """Parent of a --gpus N run started without a launcher: one child per rank, rank 0's stdout relayed.
+    Returns the exit status for the parent.  Nothing here touches the GPU (no torch import)."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    children = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                         stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    status = 0
+    try:
+        pending = set(range(n_ranks))
+        out0 = b""
+        while pending:
+            for r in sorted(pending):
+                rc = children[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = children[0].stdout.read()
+                if rc != 0:
+                    sys.stderr.write("bench.py: rank %d exited with status %d\n" % (r, rc))
+                    status = status or (rc if rc > 0 else 1)
+            if status:
+                break
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for c in children:  # a failed rank leaves its peers waiting in a collective: end exactly those processes
+            if c.poll() is None:
+                c.terminate()
+        for c in children:
+            try:
+                c.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                c.kill()
+    if status == 0:
+        lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+        if len(lines) != 1:
+            sys.stderr.write("bench.py: rank 0 printed %d JSON lines\n" % len(lines))
+            return 1
+        print(lines[0])
+    return status
+
+
 class ShardedSolveJob(object):
     """The benchmark step of one rank: solve the rank's problems into one of ``n_sets`` sets of result
     tensors, then hand that set to the gather pipeline (N > 1), which moves it to rank 0 while the next
@@ -102,9 +161,12 @@ class ShardedSolveJob(object):
     """
     GATHERED = ("J", "iters", "status", "xs", "us")
 
-    def __init__(self, solve_into, out_sets, pipe=None, before_submit=None):
+    def __init__(self, solve_into, out_sets, pipe=None, before_submit=None, mark=None):
         self.solve_into, self.out_sets, self.pipe, self.before_submit = solve_into, out_sets, pipe, before_submit
         self.n_steps = 0
+        # mark(): a point in the stream's time; taken after every solve and after the gathers have been drained,
+        # so that the part of the last gather that no solve hides can be reported
+        self.mark, self.solve_end, self.drained = mark, None, None
 
     def step(self):
         slot = self.n_steps % len(self.out_sets)
@@ -113,6 +175,8 @@ class ShardedSolveJob(object):
         if self.pipe is not None:
             self.pipe.reclaim(slot)  # the set's previous gather is ordered before the solve that overwrites it
         self.solve_into(out)
+        if self.mark is not None:
+            self.solve_end = self.mark()
         if self.pipe is not None:  # the only exchange of the path: results to rank 0
             if self.before_submit is not None:
                 self.before_submit()
@@ -122,6 +186,8 @@ class ShardedSolveJob(object):
     def finish(self):
         if self.pipe is not None:
             self.pipe.drain()  # orders the stream behind every gather issued so far
+        if self.mark is not None:
+            self.drained = self.mark()
 
     def last_slot(self):
         return (self.n_steps - 1) % len(self.out_sets)
@@ -183,7 +249,7 @@ def main_large(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d runs under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -244,6 +310,7 @@ def main_large(args):
             "config": {"workload": "synthetic non-linear system n=32, m=8, T=200, box limits +-1, %d problems per GPU, "
                                    "<=200 iterations, tol 1e-4, 30-alpha schedule" % B,
                        "problems_per_gpu": B, "horizon": TL, "parallelism": "batch-sharded x%d" % world,
+                       "ranks_seen": int(dist.get_world_size()) if world > 1 else 1,
                        "mean_iterations_per_solve": float(iters.mean()), "max_iterations": int(iters.max()),
                        "converged_fraction": float((status == 1).mean())},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -344,6 +411,52 @@ def cartpole_roofline(B, iters, kernel_ms, chunked):
     return roof
 
 
+class _Device(object):
+    """What the timed loop needs from the device: the real thing on a GPU; with ILQR_BENCH_STUB=1 (a test hook,
+    see stub_solve) host tensors and the wall clock, so that the launcher, the process group, the sharding and
+    the gather run on a machine without a GPU."""
+
+    def __init__(self, torch, local_rank, stub):
+        self.torch, self.stub = torch, stub
+        if stub:
+            self.dev = torch.device("cpu")
+        else:
+            torch.cuda.set_device(local_rank)
+            self.dev = torch.device("cuda", local_rank)
+
+    def synchronize(self):
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def mark(self):
+        """A point in the current stream's time (device event) or, for the stub, in wall-clock time."""
+        if self.stub:
+            return time.perf_counter()
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def ms_between(self, a, b):
+        return (b - a) * 1e3 if self.stub else a.elapsed_time(b)
+
+
+def stub_solve(x0, us0, out):
+    """ILQR_BENCH_STUB=1 only (CPU test of the N > 1 wiring): stands in for the device solve with a
+    deterministic function of the inputs, so that the gathered slices can be told apart and checked."""
+    B = x0.shape[0]
+    out["J"][:B] = (x0 * x0).sum(1) + (us0 * us0).sum((1, 2))
+    out["iters"][:B] = 1 + (x0[:, 0].abs() * 7).to(out["iters"].dtype)
+    out["status"][:B] = 1
+    out["xs"][:B] = x0[:, None, :]
+    out["us"][:B] = us0
+
+
+def bits_checksum(t):
+    """Order-independent checksum of a float64 tensor's bits (wrapping int64 sum)."""
+    import torch
+    return t.contiguous().view(torch.int64).sum().reshape(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=("cartpole", "large"), default="cartpole",
@@ -359,6 +472,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher around us: be the launcher
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if os.environ.get("ILQR_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["ILQR_BENCH_WATCHDOG"]), exit=True)
@@ -367,21 +484,23 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ilqr_amd import _hip, compaction, sharding
+    from ilqr_amd import compaction, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
-                         % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d runs under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
     # ILQR_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
     # (ranks share devices; RCCL refuses that).  The measured configuration is always nccl (= RCCL).
     backend = os.environ.get("ILQR_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
+    stub = os.environ.get("ILQR_BENCH_STUB") == "1"
+    if stub and backend == "nccl":
+        raise SystemExit("ILQR_BENCH_STUB=1 (no device solve) needs ILQR_BENCH_BACKEND=gloo")
+    if backend != "nccl" and not stub:
         local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    D = _Device(torch, local_rank, stub)
+    dev = D.dev
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -389,9 +508,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    Q, R, Qt, xg = cartpole_cost()
-    M = _hip.Model(T, Q, R, Qt, xg, None, [-5.0], [5.0], dt=0.05)
-    O = _hip.Opts()
     if args.total is not None:  # strong scaling: one global batch (generated per 16384-problem block, so that a
         # rank only materialises its own slice), cut into contiguous slices
         sizes = sharding.shard_sizes(args.total, world)
@@ -421,38 +537,51 @@ def main():
                      J=torch.zeros(rows, dtype=f64, device=dev), mu=torch.zeros(rows, dtype=f64, device=dev),
                      iters=torch.zeros(rows, dtype=i32, device=dev),
                      status=torch.zeros(rows, dtype=i32, device=dev)) for _ in range(n_sets)]
-    delta = torch.empty(B, dtype=f64, device=dev)
-    k = torch.empty((B, T, 1), dtype=f64, device=dev)
-    K = torch.empty((B, T, 1, 5), dtype=f64, device=dev)
+    if stub:
+        def solve_into(out):
+            stub_solve(x0, us0, out)
+    else:
+        from ilqr_amd import _hip
+        Q, R, Qt, xg = cartpole_cost()
+        M = _hip.Model(T, Q, R, Qt, xg, None, [-5.0], [5.0], dt=0.05)
+        O = _hip.Opts()
+        delta = torch.empty(B, dtype=f64, device=dev)
+        k = torch.empty((B, T, 1), dtype=f64, device=dev)
+        K = torch.empty((B, T, 1, 5), dtype=f64, device=dev)
 
-    def solve_into(out):
-        # a freshly constructed solver per step: delta_ = 2, k_ = K_ = 0 (ilqr_core.py:58-65)
-        delta.fill_(2.0)
-        k.zero_()
-        K.zero_()
-        mine = {name: t[:B] for name, t in out.items()}  # (a view of the leading rows is contiguous)
-        if chunked:
-            res = _hip.solve_chunked(M, O, x0, us0, compaction.COMPACT_CHUNK, delta=delta, k=k, K=K,
-                                     workspace=ws[0], out=mine)
-        else:
-            res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws[0], out=mine)
-        ws[0] = res["workspace"]
+        def solve_into(out):
+            # a freshly constructed solver per step: delta_ = 2, k_ = K_ = 0 (ilqr_core.py:58-65)
+            delta.fill_(2.0)
+            k.zero_()
+            K.zero_()
+            mine = {name: t[:B] for name, t in out.items()}  # (a view of the leading rows is contiguous)
+            if chunked:
+                res = _hip.solve_chunked(M, O, x0, us0, compaction.COMPACT_CHUNK, delta=delta, k=k, K=K,
+                                         workspace=ws[0], out=mine)
+            else:
+                res = _hip.solve(M, O, x0, us0, delta=delta, k=k, K=K, workspace=ws[0], out=mine)
+            ws[0] = res["workspace"]
 
     pipe = sharding.GatherPipeline(depth=n_sets, dst=0) if world > 1 else None
     # rehearsal only: gloo's gathers of GPU tensors hang behind a running kernel
     job = ShardedSolveJob(solve_into, out_sets, pipe,
-                          before_submit=torch.cuda.synchronize if backend != "nccl" else None)
+                          before_submit=D.synchronize if backend != "nccl" else None,
+                          mark=D.mark if world > 1 else None)
 
     def barrier():
-        torch.cuda.synchronize()
+        D.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        D.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    elapsed = run_steps(job, args.steps, args.warmup, barrier,
-                        record=lambda i, what: ev[i][0 if what == "start" else 1].record())
-    step_ms_events = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    ev = [[None, None] for _ in range(args.steps)]
+
+    def record(i, what):
+        ev[i][0 if what == "start" else 1] = D.mark()
+    elapsed = run_steps(job, args.steps, args.warmup, barrier, record=record)
+    # from the end of the last solve to the arrival of its results on rank 0: the gather no solve overlaps
+    gather_exposed_ms = D.ms_between(job.solve_end, job.drained) if world > 1 else None
+    step_ms_events = float(np.mean([D.ms_between(a, b) for a, b in ev]))
 
     t = torch.tensor([elapsed], dtype=f64, device=dev)
     if world > 1:
@@ -460,6 +589,12 @@ def main():
     elapsed = float(t.item())
 
     out_buf = out_sets[job.last_slot()]
+    # every rank's checksum of the costs it produced in the last step, collected on rank 0 beside the data
+    sums = None
+    if world > 1:
+        mine = bits_checksum(out_buf["J"][:B])
+        sums = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, sums, dst=0)
     iters = out_buf["iters"][:B].cpu().numpy().astype(np.int64)
     status = out_buf["status"][:B].cpu().numpy()
     J = out_buf["J"][:B].cpu().numpy()
@@ -469,9 +604,12 @@ def main():
         solves_per_s = total * args.steps / elapsed
         max_iters = int(iters.max())
         gathered_ok = None
-        if pipe is not None:  # the last step's results as rank 0 received them: its own slice must be intact
-            g = pipe.result(job.last_slot(), "J")
-            gathered_ok = bool(torch.equal(g.reshape(world, rows)[0, :B], out_buf["J"][:B]))
+        if pipe is not None:
+            # the last step's results as rank 0 received them: the slice of EVERY rank must carry the checksum
+            # that rank computed before sending, and rank 0's own slice must be the tensor it solved into
+            g = pipe.result(job.last_slot(), "J").reshape(world, rows)
+            per_rank = [bool(torch.equal(bits_checksum(g[r, :sizes[r]]), sums[r])) for r in range(world)]
+            gathered_ok = bool(all(per_rank) and torch.equal(g[0, :B], out_buf["J"][:B]))
         if args.total is not None:
             workload = ("%d cart-pole swing-up problems in all, cut into %d contiguous slices (%s per GPU), T=100, "
                         "n=5, m=1, control limits +-5 active, <=200 iterations, tol 1e-4, 30-alpha schedule"
@@ -499,11 +637,18 @@ def main():
                                 else "single launch",
                        "mean_iterations_per_solve": float(iters.mean()), "max_iterations": max_iters,
                        "converged_fraction": float((status == 1).mean()), "mean_final_cost": float(J.mean())},
-            "roofline": cartpole_roofline(B, iters, step_ms_events, chunked),
         }
-        if gathered_ok is not None:
+        if not stub:
+            line["roofline"] = cartpole_roofline(B, iters, step_ms_events, chunked)
+        else:
+            line["config"]["stub"] = "ILQR_BENCH_STUB=1: no device solve ran; this line is not a measurement"
+        if world > 1:
+            line["config"]["ranks_seen"] = int(dist.get_world_size())
+            line["config"]["collective_backend"] = backend
             line["config"]["gather_check"] = gathered_ok
-        if world == 1 and not args.no_cpu_baseline:
+            line["config"]["gather_check_per_rank"] = per_rank
+            line["config"]["gather_exposed_ms_last_step"] = gather_exposed_ms
+        if world == 1 and not args.no_cpu_baseline and not stub:
             threads = max(1, min(16, os.cpu_count() or 1))
             line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, B), threads)
         print(json.dumps(line))

@@ -165,14 +165,19 @@ class Opts:
         self.max_iter = int(max_iter)
 
     def carrying(self, dJ):
-        """The C struct with ``dJ_carry`` pointing at ``dJ`` ([2, B] fp64 device tensor or None) for one call:
-        the expected-improvement sums Delta_J1 / Delta_J2 of a solve that is cut into several calls."""
+        """A copy of the C struct for ONE call, with ``dJ_carry`` pointing at ``dJ`` ([2, B] fp64 device tensor or
+        None): the expected-improvement sums Delta_J1 / Delta_J2 of a solve that is cut into several calls.  The
+        shared struct is never modified (no pointer to a caller's temporary outlives the call), and the copy keeps
+        the tensor and the step-size array alive for as long as it exists."""
         import torch
         if dJ is not None:
             assert dJ.dim() == 2 and dJ.shape[0] == 2
             _req(dJ, torch.float64)
-        self.c.dJ_carry = None if dJ is None else dJ.data_ptr()
-        return self.c
+        c = OptsC()
+        C.memmove(C.byref(c), C.byref(self.c), C.sizeof(OptsC))
+        c.dJ_carry = None if dJ is None else dJ.data_ptr()
+        c.keep_alive_ = (self.alphas, dJ)
+        return c
 
 
 def _ptr(t):

@@ -5,6 +5,8 @@
 // is one contiguous 512-byte segment.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -1761,7 +1763,7 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
         status_out[gb] = status;
         W.sel_traj[gb] = cur;
         W.sel_gain[gb] = gcur;
-        if (O.dJ_carry != nullptr) {
+        if (O.mu_from_array && O.dJ_carry != nullptr) { // only a solve that is being continued carries the sums
             O.dJ_carry[gb] = dJ1;
             O.dJ_carry[B + gb] = dJ2;
         }
@@ -2071,7 +2073,7 @@ inline dim3 tile_grid(int64_t B, int64_t R) { return dim3((unsigned)((B + 63) / 
 
 extern "C" {
 
-int ilqr_version(void) { return 100; }
+int ilqr_version(void) { return 101; }
 
 const char* ilqr_status_string(int s)
 {
@@ -2266,7 +2268,24 @@ size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B)
 // of each belongs to problem b of this launch; idx == nullptr: row b), with the per-problem SCALARS (delta, J,
 // mu, iters, status, trace) compact, [B].  The chunked solve continues its running problems this way without
 // staging copies of their trajectories and gains.
-static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+static // Compute units of the current device, looked up once per device and process (the launch-shape rules below are
+// on the path of every solve, closed-loop re-solves of ~0.1 ms included).
+int device_cu_count()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v > 0)
+        return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+        return 256;
+    cached[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
+int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
                                  const double* us_init, double* delta, double* k, double* K, double* xs,
                                  double* us, double* J, double* mu, int32_t* iters, int32_t* status,
                                  const ilqr_trace* trace, void* workspace, size_t workspace_bytes, void* stream,
@@ -2342,13 +2361,7 @@ static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts,
     // or two groups of two; groups that find no CU would wait for a second round.  Hence: three wavefronts per
     // group while the groups number at most the CUs, two while at most twice the CUs; 32 problems per group while
     // even that many groups fit, 64 otherwise.  ILQR_SOLVE_GROUP=1/2/3 overrides the choice.
-    int n_cu = 256;
-    {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n_cu = v;
-    }
+    const int n_cu = device_cu_count();
     const int64_t groups64 = (B + 63) / 64, groups32 = (B + 31) / 32;
     int group = 1; // wavefronts per group of problems
     if (groups64 <= n_cu)
@@ -2608,13 +2621,7 @@ int ilqr_solve_batched_chunked(const ilqr_model* model, const ilqr_opts* opts, i
     // more runs a second round for the overhang that costs most of a full one (67185 problems take as long
     // as 77654), so while the running set is within a sixth of a round above a whole number of rounds the
     // chunks are a quarter as long: the set is re-counted sooner and drops a round earlier.
-    int64_t round_problems = 256 * 4 * WAVE;
-    {
-        int dev = 0, n_cu = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
-            round_problems = (int64_t)n_cu * 4 * WAVE;
-    }
+    const int64_t round_problems = (int64_t)device_cu_count() * 4 * WAVE;
     for (;;) {
         const int64_t over = n % round_problems; // problems beyond the last full round
         const bool overhang = n > round_problems && over > 0 && over <= round_problems / 6;

@@ -1341,7 +1341,7 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P, const LSolveOpt
         mu_out[b] = mu;
         iters_out[b] = iters;
         status_out[b] = status;
-        if (O.dJ_carry != nullptr) {
+        if (O.mu_from_array && O.dJ_carry != nullptr) { // only a solve that is being continued carries the sums
             O.dJ_carry[b] = dJ1;
             O.dJ_carry[B + b] = dJ2;
         }

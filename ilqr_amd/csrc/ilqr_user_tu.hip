@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
         mu_out[b] = mu;
         iters_out[b] = iters;
         status_out[b] = status;
-        if (O.dJ_carry != nullptr) {
+        if (O.mu_from_array && O.dJ_carry != nullptr) { // only a solve that is being continued carries the sums
             O.dJ_carry[b] = dJ1;
             O.dJ_carry[B + b] = dJ2;
         }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
         mu_out[b] = mu;
         iters_out[b] = iters;
         status_out[b] = status;
-        if (O.dJ_carry != nullptr) {
+        if (O.mu_from_array && O.dJ_carry != nullptr) { // only a solve that is being continued carries the sums
             O.dJ_carry[b] = dJ1;
             O.dJ_carry[B + b] = dJ2;
         }

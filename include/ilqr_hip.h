@@ -82,8 +82,10 @@ typedef struct ilqr_opts {
     /* DEVICE [2, B] or NULL.  Delta_J1 and Delta_J2 of update_u (ilqr_core.py:278-279, :289) are loop-carried:
      * after a backward pass that gives up at mu_max (:291-299) the line search runs on the sums of the previous
      * iteration (:305).  A caller that cuts one solve into several calls (mu_init >= 0) hands this array to each
-     * of them: it is read on entry when mu_init >= 0 (a fresh solve starts from zeros, :278-279) and written on
-     * exit, Delta_J1 of problem b at [b], Delta_J2 at [B + b]. */
+     * of them: it is read on entry and written on exit (Delta_J1 of problem b at [b], Delta_J2 at [B + b]) ONLY
+     * when mu_init >= 0; a fresh solve (mu_init < 0) starts from zeros (:278-279) and never touches the array.
+     * The struct has grown by this trailing field (ilqr_version() >= 101): zero-initialise every ilqr_opts
+     * (`ilqr_opts o = {0};` or memset) before filling it, so that fields a caller does not know stay NULL / 0. */
     double* dJ_carry;
 } ilqr_opts;
 
@@ -179,8 +181,11 @@ int ilqr_boxqp_batched(int64_t B, int32_t m, const double* H, const double* g, c
  *   workspace: device buffer of at least ilqr_solve_workspace_bytes(model, B).
  * The launch shape (problems per wavefront, wavefronts per workgroup, and how many wavefronts share the
  * backward sweep of one group of problems) is chosen from B, T and max_iter and never changes a result; for
- * experiments the environment variables ILQR_SOLVE_LPW (16, 32 or 64), ILQR_SOLVE_BLOCK (64, 128 or 256
- * threads) and ILQR_SOLVE_GROUP (1, 2 or 3 wavefronts per group) override it. */
+ * experiments the environment variables ILQR_SOLVE_GROUP (1, 2 or 3 wavefronts per group), ILQR_SOLVE_LPW
+ * (16, 32 or 64 problems per group) and ILQR_SOLVE_BLOCK (64, 128 or 256 threads; only with one wavefront
+ * per group -- a group of two or three wavefronts IS the workgroup, and the variable is ignored) override it
+ * (every combination is covered by the launch-shape parity test).  They are read when the launch is issued; a launch recorded in a HIP graph keeps the
+ * shape it was captured with. */
 size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B);
 int ilqr_solve_batched(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
                        const double* us_init, double* delta, double* k, double* K, double* xs,

@@ -336,3 +336,34 @@ def test_cartpole_dynamics_point_evaluations():
     assert eq(dyn.f(x[3], u[3], 0), f[3]) and dyn.f_x(x[3], u[3], 0).shape == (5, 5)
     assert dyn.f_u(x[3], u[3], 0).shape == (5, 1)
     assert np.array_equal(dyn.upper_bound, [7.0]) and np.array_equal(dyn.lower_bound, [-7.0])
+
+
+def test_a_fresh_solve_leaves_the_carry_array_alone():
+    """ilqr_opts.dJ_carry belongs to solves that are being continued (mu_init >= 0): a fresh solve
+    (mu_init < 0) given a non-NULL pointer neither reads nor writes it -- on the cart-pole path and on the
+    large-state path -- and a continued one does write it."""
+    from ilqr_amd import _hip
+    from ilqr_amd.synthetic import SyntheticWorkload
+    dev = torch.device("cuda:0")
+    B, T = 70, 30
+    x0, us0 = co.cartpole_batch(B, T=T, seed_x=5, seed_u=6)
+    Mo = co.cartpole_model(T=T)
+    M = _hip.Model(T, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper)
+    x0d, us0d = torch.tensor(x0, device=dev), torch.tensor(us0, device=dev)
+    canary = torch.full((2, B), 12345.678, dtype=torch.float64, device=dev)
+    dJ = canary.clone()
+    plain = _hip.solve(M, _hip.Opts(max_iter=6), x0d, us0d)
+    fresh = _hip.solve(M, _hip.Opts(max_iter=6), x0d, us0d, dJ=dJ)
+    assert torch.equal(dJ, canary)
+    assert torch.equal(fresh["us"], plain["us"]) and torch.equal(fresh["J"], plain["J"])
+    cont = _hip.solve(M, _hip.Opts(max_iter=2, mu_from_array=True), x0d, fresh["us"], delta=fresh["delta"], k=fresh["k"],
+                      K=fresh["K"], mu=fresh["mu"].clone(), dJ=dJ)
+    assert not torch.equal(dJ, canary) and int(cont["iters"].max()) >= 1
+
+    wl = SyntheticWorkload(T=12)
+    ML = wl.device_model()
+    lx0, lus = wl.batch(9)
+    lx0, lus = torch.tensor(lx0, device=dev), torch.tensor(lus, device=dev)
+    dJ = torch.full((2, 9), 12345.678, dtype=torch.float64, device=dev)
+    _hip.large_solve(ML, _hip.Opts(max_iter=3), lx0, lus, dJ=dJ)
+    assert torch.equal(dJ, torch.full_like(dJ, 12345.678))

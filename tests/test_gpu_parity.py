@@ -6,6 +6,8 @@ integer output (iteration counts, boxQP result codes, active sets, line-search
 indices) identical.  The fixtures recorded from the reference's own solver are
 matched to 1e-9 relative on costs with identical discrete decisions.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -402,7 +404,8 @@ def test_plant_step_bit_exact(hip):
 @pytest.mark.parametrize("B", [16384, 20480, 32768, 40000])
 def test_full_size_batch_properties(hip, B):
     """C1 at its full size (16384 problems: three wavefronts per group of 64) and at the sizes that take the other
-    launch shapes (two wavefronts per group up to 32768, one beyond): properties that need no oracle run."""
+    launch shapes (two wavefronts per group up to 32768, one beyond): properties that need no oracle run, and every
+    problem of every launch compared with the oracle."""
     x0, us0 = co.cartpole_batch(B)
     Mo = co.cartpole_model()
     M = hip_model(hip, Mo)
@@ -422,16 +425,34 @@ def test_full_size_batch_properties(hip, B):
     xs_bm, J2 = hip.rollout_cost_bm(M, B, hip.pack_bm(out["xs"][:, 0].contiguous()), hip.pack_bm(out["us"]))
     assert eq(hip.unpack_bm(xs_bm, B, (101, 5)).cpu().numpy(), out["xs"].cpu().numpy())
     assert eq(J2.cpu().numpy(), J)
-    # control limits: the feed-forward part respects them; a sample agrees with the oracle bit for bit
-    idx = np.arange(0, B, 331)
-    ref = co.solve(Mo, co.Opts(), x0[idx], us0[idx], nthreads=8, trace=False)
-    assert np.array_equal(ref["iters"], iters[idx]) and eq(ref["J"], J[idx])
-    assert eq(ref["us"], out["us"].cpu().numpy()[idx])
+    # EVERY problem of the launch against the oracle, bit for bit (the oracle solves them on the host's cores)
+    ref = co.solve(Mo, co.Opts(), x0, us0, nthreads=16, trace=False)
+    assert np.array_equal(ref["iters"], iters) and np.array_equal(ref["status"], status)
+    for key in ("J", "us", "xs", "k", "K", "mu", "delta"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
     # sharding: a slice solved alone gives the same bits as inside the big batch
     lo, hi = 4096 + 17, 4096 + 17 + 1000
     part = hip.solve(M, hip.Opts(), dev(x0[lo:hi]), dev(us0[lo:hi]))
     assert eq(part["us"].cpu().numpy(), out["us"].cpu().numpy()[lo:hi])
     assert np.array_equal(part["iters"].cpu().numpy(), iters[lo:hi])
+
+
+@pytest.mark.parametrize("B", [16384, 32768])
+def test_every_problem_of_the_benchmark_batch_against_the_oracle(hip, B):
+    """The batch bench.py times (bench.make_batch(B, 0)) in the launch shapes it is timed in -- 16384 problems:
+    three wavefronts per group of 64 problems on every CU; 32768: two wavefronts per group -- with every
+    problem's costs, controls, states, gains, regularisation state, iteration count and status == the oracle's."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    x0, us0 = bench.make_batch(B, 0)
+    Mo = co.cartpole_model()
+    ref = co.solve(Mo, co.Opts(), x0, us0, nthreads=16, trace=False)
+    out = hip.solve(hip_model(hip, Mo), hip.Opts(), dev(x0), dev(us0))
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "us", "xs", "k", "K", "mu", "delta"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
 
 
 @pytest.mark.parametrize("seed", [11, 12])

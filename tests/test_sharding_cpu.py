@@ -172,3 +172,44 @@ def test_sector_granular_factor():
     assert bench.sector_granular_factor([5] * 16) == 1.0
     assert bench.sector_granular_factor([10] + [0] * 7) == 8.0
     assert abs(bench.sector_granular_factor([4, 2] * 4 + [1] * 8) - (32 + 8) / 32.0) < 1e-12
+
+
+def _run_bench(argv, env_extra, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr.decode()
+
+
+@pytest.mark.parametrize("argv, sizes", [(["--gpus", "2", "--batch", "48"], [48, 48]),
+                                         (["--gpus", "3", "--total", "100"], [34, 33, 33])])
+def test_bench_launches_its_own_ranks_and_checks_every_slice(argv, sizes):
+    """`bench.py --gpus N` without a launcher: the parent starts N ranks, relays ONE JSON line, and the line
+    says how many ranks the collective saw and that every rank's gathered slice carries that rank's checksum.
+    (ILQR_BENCH_STUB=1 replaces the device solve, gloo the RCCL backend: no GPU here.)"""
+    rc, lines, err = _run_bench(argv + ["--steps", "2", "--warmup", "1"],
+                                {"ILQR_BENCH_BACKEND": "gloo", "ILQR_BENCH_STUB": "1"})
+    assert rc == 0, err
+    assert len(lines) == 1
+    line = lines[0]
+    cfg = line["config"]
+    assert line["n_gpus"] == len(sizes) and cfg["ranks_seen"] == len(sizes)
+    assert cfg["problems_total"] == sum(sizes) and cfg["problems_per_gpu"] == sizes[0]
+    assert cfg["gather_check"] is True and cfg["gather_check_per_rank"] == [True] * len(sizes)
+    assert cfg["gather_exposed_ms_last_step"] >= 0.0
+    assert line["value"] > 0 and line["steps"] == 2 and line["warmup"] == 1
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies makes the parent exit non-zero and print no result line (here: every rank refuses the
+    stub without the gloo backend)."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"ILQR_BENCH_STUB": "1"},
+                                timeout=120)
+    assert rc != 0 and lines == []
+    assert "exited with status" in err

@@ -74,3 +74,45 @@ def test_static_workspace_solve_refuses_what_does_not_fit(hip):
     with pytest.raises(hip.IlqrHipError, match="workspace"):
         hip.solve_static(M, hip.Opts(), torch.tensor(x0_h, device=dev), torch.tensor(us_h, device=dev), delta, k, K,
                          _outputs(B, T, dev))
+
+
+def test_static_workspace_solve_can_be_captured_in_a_graph_and_replayed(hip):
+    """What the entry point is for: after one warm-up call it can be recorded in a HIP graph (recording fails on
+    any allocation or synchronisation inside the call) and replayed on new inputs written into the same
+    tensors; every replay equals ilqr_solve_batched on those inputs.  All calls on a GPU share the library's
+    workspace, so replays (and any other caller of this entry point) must not overlap: they are serialised on
+    one stream here."""
+    dev = torch.device("cuda:0")
+    T, B = 20, 400
+    M = _model(hip, T)
+    O = hip.Opts(max_iter=12)
+    f64 = torch.float64
+    x0 = torch.empty((B, 5), dtype=f64, device=dev)
+    us0 = torch.empty((B, T, 1), dtype=f64, device=dev)
+    delta = torch.empty(B, dtype=f64, device=dev)
+    k = torch.empty((B, T, 1), dtype=f64, device=dev)
+    K = torch.empty((B, T, 1, 5), dtype=f64, device=dev)
+    out = _outputs(B, T, dev)
+
+    def load(seed):
+        x0_h, us_h = _batch(B, T, seed)
+        x0.copy_(torch.tensor(x0_h))
+        us0.copy_(torch.tensor(us_h))
+        delta.fill_(2.0)
+        k.zero_()
+        K.zero_()
+
+    load(20)
+    hip.solve_static(M, O, x0, us0, delta, k, K, out)  # warm-up: the per-device set-up happens here
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hip.solve_static(M, O, x0, us0, delta, k, K, out)
+    for seed in (21, 22):
+        load(seed)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = hip.solve(M, O, x0.clone(), us0.clone())
+        for key in ("xs", "us", "J", "mu", "iters", "status"):
+            assert torch.equal(out[key], ref[key]), (seed, key)
+        assert torch.equal(delta, ref["delta"]) and torch.equal(k, ref["k"]) and torch.equal(K, ref["K"])
