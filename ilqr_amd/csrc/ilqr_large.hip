@@ -388,6 +388,45 @@ __device__ __forceinline__ unsigned v8_mask(bool fa, bool fb)
     return m;
 }
 
+// Armijo loop, proof of exhaustion.  Near a solution the reference's backtracking loop (ilqr_boxQP.py:151-159)
+// often runs until the step falls below min_step: the search direction is tiny, every candidate's objective
+// equals the old one up to rounding, and (vc - old) / (sdotg + 1e-10) stays below the Armijo constant because of
+// the 1e-10.  Literal evaluation of those ~480 trips is the most expensive path of a backward step, so before
+// it is started the wave tries to PROVE that every trip from step size `st` on continues:
+//   |xc_i - x_i| <= E_i = (1 + 1e-7) st |s_i| + 1.2e-16 |x_i|      (two roundings; clamping only shortens it, as
+//                                                                   lo <= x <= hi)
+//   exact objective v:  |v(xc) - v(x)| <= sum_i E_i G_i + 1/2 sum_ij E_i |H_ij| E_j,   with
+//       G_i >= |g_i + 1/2 sum_j (H_ij + H_ji) x_j|,  G_i = 1.01 (|grad_i| + 1.1e-15 (|g_i| + sum_j |H_ij| |x_j|)
+//                                                               + 1/2 sum_j |H_ij - H_ji| |x_j|)
+//       (computed gradient + its rounding error + the asymmetry of the computed Q_uu)
+//   computed objective (an 8-term chain, 8 chains of 8 terms, a chain over their results, one add):
+//       |V(z) - v(z)| <= 3e-15 A,   A = sum_i X_i |g_i| + sum_ij X_i |H_ij| X_j,  X_i = |x_i| + E_i >= |z_i|
+//   hence |vc - old| <= NUM = 1.001 (sum E G + 1/2 E|H|E + 6e-15 A) + 1e-200, and the computed slope satisfies
+//   |sdotg| <= S = 1.001 sum_i E_i |grad_i|, so the denominator is >= 0.999 (1e-10 - S).
+// If S < 1e-10 and NUM < armijo * 0.999 (1e-10 - S), the quotient is below armijo at this step size, and -- all
+// bounds grow with st -- at every smaller one: the loop ends at trip n_exhaust with result 2 and that trip's
+// candidate, which is then evaluated directly.  Any NaN or infinity makes a comparison false (no proof, literal
+// evaluation).  The bounds are generous by the factors shown; sums are MFMA chains of non-negative terms.
+__device__ __forceinline__ bool armijo_exhausts(const H8& H, const V8& g, const V8& x, const V8& grad,
+                                                const V8& search, double st, double armijo)
+{
+    const V8 ax{fabs(x.a), fabs(x.b)}, ag{fabs(g.a), fabs(g.b)}, agr{fabs(grad.a), fabs(grad.b)};
+    const V8 E{1.0000001 * st * fabs(search.a) + 1.2e-16 * ax.a, 1.0000001 * st * fabs(search.b) + 1.2e-16 * ax.b};
+    const V8 X{ax.a + E.a, ax.b + E.b};
+    const double hta = fabs(H.t.a), htb = fabs(H.t.b); // |H| with rows on the k axis: sum_j |H_ij| v_j
+    const d4 hax = mf2(hta, htb, ax.a, ax.b);
+    const d4 asy = mf2(fabs(H.t.a - H.n.a), fabs(H.t.b - H.n.b), ax.a, ax.b);
+    const V8 G{1.01 * (agr.a + 1.1e-15 * (ag.a + hax[0]) + 0.5 * asy[0]),
+               1.01 * (agr.b + 1.1e-15 * (ag.b + hax[1]) + 0.5 * asy[1])};
+    const d4 hE = mf2(hta, htb, E.a, E.b);
+    const d4 hX = mf2(hta, htb, X.a, X.b);
+    const double d1 = v8_dot(E, G) + 0.5 * v8_dot(E, V8{hE[0], hE[1]});
+    const double A = v8_dot(X, ag) + v8_dot(X, V8{hX[0], hX[1]});
+    const double NUM = 1.001 * (d1 + 6e-15 * A) + 1e-200;
+    const double S = 1.001 * v8_dot(E, agr);
+    return (S < 1e-10) && (armijo > 0.0) && (NUM < armijo * (0.999 * (1e-10 - S)));
+}
+
 // H: Q_uu, finite and positive definite (the caller has checked); steps: the wave's step table.
 // On entry Q.x holds the warm start and Q.Lf / Q.rd / Q.fmask the factor of the full H (the caller
 // needed it for the warm start): a factorisation for a free set that Lf already belongs to is not
@@ -518,6 +557,14 @@ __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR
                 x.b = __shfl(xc.b, (ln & 48) | cs);
                 value = rl64(vc, 16 * (cs & 3) + cs);
                 found = true;
+            } else if (armijo_exhausts(H, gV, x, grad, search, steps[16], O.armijo)) {
+                // every trip from 16 on continues: the loop ends at trip n_exhaust with that trip's candidate
+                const double se = steps[O.n_exhaust];
+                x = V8{lclamp(loV.a, hiV.a, x.a + se * search.a), lclamp(loV.b, hiV.b, x.b + se * search.b)};
+                value = h8_value(H, gV, x);
+                n_bt += O.n_exhaust;
+                result = 2;
+                found = true;
             }
         }
         if (!found) {
@@ -573,6 +620,17 @@ __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR
                     for (int i = 0; i < LM; ++i)
                         xu[i] = rl64(xc[i], w);
                     value = rl64(vc, w);
+                    break;
+                }
+                if (tb + 64 < O.n_exhaust && armijo_exhausts(H, gV, x, grad, search, steps[tb + 64], O.armijo)) {
+                    const double se = steps[O.n_exhaust];
+                    const V8 xe{lclamp(loV.a, hiV.a, x.a + se * search.a), lclamp(loV.b, hiV.b, x.b + se * search.b)};
+                    value = h8_value(H, gV, xe);
+                    n_bt += O.n_exhaust;
+                    result = 2;
+#pragma unroll
+                    for (int i = 0; i < LM; ++i)
+                        xu[i] = i < 4 ? rl64(xe.a, 16 * (i & 3)) : rl64(xe.b, 16 * (i & 3));
                     break;
                 }
             }

@@ -312,3 +312,28 @@ def test_large_derivative_streams_bit_exact(hip, path):
         ref = co.derivatives(Mo, xs[b], us[b])
         for key in ("fx", "fu", "lx", "lu", "lxx", "luu", "lux", "lxT", "lxxT"):
             assert eq(out[key][b].cpu().numpy(), ref[key]), (b, key)
+
+
+@pytest.mark.parametrize("qp", [dict(), dict(qp_step_dec=0.6), dict(qp_armijo=0.3, qp_min_step=1e-12),
+                                dict(qp_step_dec=0.97, qp_min_step=1e-6)])
+def test_large_backward_on_converged_trajectories(hip, qp):
+    """Backward sweeps on trajectories the solver has (nearly) converged on: there the boxQP's Armijo loop runs
+    until the step falls below min_step in a large share of the time steps (ilqr_boxQP.py:151-159; the 1e-10
+    in its test), the path on which the device code replaces literal evaluation of the trips by a proof of
+    their outcome.  Gains, expected improvements, result codes, free sets and the trip counters must equal the
+    oracle's literal loop, for several settings of the loop's options."""
+    T, B = 200, 40
+    Mo, M = models(hip, T)
+    x0, us0 = co.synthetic_batch(B, T=T)
+    sol = co.solve(Mo, co.Opts(max_iter=9), x0, us0, nthreads=16, trace=False)  # most problems need 8-12
+    ref = co.backward(Mo, co.Opts(**qp), sol["xs"], sol["us"], sol["mu"])
+    out = hip.large_backward(M, hip.Opts(**qp), dev(sol["xs"]), dev(sol["us"]), dev(sol["mu"]))
+    info, dJ = out["info"].cpu().numpy(), out["dJ"].cpu().numpy()
+    assert np.array_equal(info[2], ref["qp_backtrack"]) and np.array_equal(info[1], ref["qp_iter"])
+    assert np.array_equal(out["qp_result"].cpu().numpy(), ref["qp_result"])
+    assert np.array_equal(out["free"].cpu().numpy(), ref["free"])
+    assert eq(out["k"].cpu().numpy(), ref["k"]) and eq(out["K"].cpu().numpy(), ref["K"])
+    assert eq(dJ[0], ref["dJ1"]) and eq(dJ[1], ref["dJ2"])
+    assert np.array_equal(info[0], ref["stopped_at"]) and np.array_equal(info[3], ref["n_clamped"])
+    exhausted = (ref["qp_result"] == 2).mean()
+    assert exhausted > 0.05, exhausted  # the path is really taken
