@@ -237,6 +237,16 @@ def load_counters(workload, batch):
     return None
 
 
+def load_critical_path():
+    """profiles/critical_path.json (scripts/chain_depth.py: lengths of the loop-carried dependent instruction chains
+    of one backward step and one rollout step, counted from the compiled code), or None."""
+    path = os.path.join(ROOT, "profiles", "critical_path.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)
+
+
 def main_large(args):
     """--workload large: the large-state configuration (synthetic n=32, m=8, T=200, box limits +-1,
     fp64 MFMA path, one problem per wavefront).  Same contract; the roofline object is flop-based."""
@@ -378,25 +388,38 @@ def cartpole_roofline(B, iters, kernel_ms, chunked):
                 "frac": moved / dur_s / 1e9 / HBM_PEAK_GBS,
                 "basis": "PMC-measured bytes" if traffic else "fused-design bytes of this run's iteration counts"}
     else:
-        # up to 32768 problems every wavefront has a SIMD to itself and the time is the latency of one
-        # wavefront's instruction stream: the resource in use is VALU issue
-        roof = {"bound": "fp64_valu_issue", "unit": "fraction of the chip's SIMD cycles with a VALU instruction "
-                                                    "in flight", "peak": 1.0,
-                "note": "at this batch size the time is the latency of the dependent fp64 chains of one group of "
-                        "problems (spread over up to three wavefronts on three SIMDs of a CU); neither VALU issue "
-                        "nor HBM is saturated, and the fraction says how much of the chip's issue capacity the "
-                        "launch uses, not how close the kernel is to a limit"}
+        # Up to 32768 problems every wavefront has a SIMD to itself and the launch lasts as long as its slowest
+        # group of problems: max_iterations x T time steps, each a backward step and a rollout step whose inputs
+        # are the outputs of the step before.  The bound of such a launch is the length of those loop-carried
+        # chains of dependent instructions x the issue interval of dependent instructions; frac = that bound /
+        # the measured time says how far the kernel is from the limit its data dependencies set.
+        cp = load_critical_path()
+        roof = {"bound": "dependent-instruction chain (latency)", "unit": "time steps/s of the slowest problem group"}
+        if cp is not None:
+            chain = cp["backward_step_chain"] + cp["rollout_step_chain"]
+            step_s = chain * cp["dependent_issue_cycles"] / cp["shader_clock_hz"]
+            n_steps = int(iters.max()) * T
+            roof.update(achieved=n_steps / dur_s, peak=1.0 / step_s, frac=n_steps * step_s / dur_s,
+                        critical_path={"ms": n_steps * step_s * 1e3, "time_steps": n_steps,
+                                       "chain_instructions_per_time_step": chain,
+                                       "backward_step_chain": cp["backward_step_chain"],
+                                       "rollout_step_chain": cp["rollout_step_chain"],
+                                       "dependent_issue_cycles": cp["dependent_issue_cycles"],
+                                       "shader_clock_hz": cp["shader_clock_hz"], "probes": cp["probes"],
+                                       "basis": "profiles/critical_path.json (scripts/chain_depth.py on "
+                                                "scripts/micro/chain_probes.hip)"})
+        else:
+            roof.update(achieved=None, peak=None, frac=None)
+        occ = {"note": "share of the chip's SIMD cycles with a vector instruction in flight (an occupancy, not a "
+                       "distance from a limit: a faster kernel shows a lower value)"}
         if cnt and cnt.get("valu_busy_frac_of_chip") is not None:
-            roof.update(achieved=cnt["valu_busy_frac_of_chip"], frac=cnt["valu_busy_frac_of_chip"],
-                        valu_busy_frac_per_wave=cnt.get("valu_busy_frac_per_wave"),
-                        simd_occupancy=cnt.get("simd_occupancy"),
-                        lane_weighted_frac=cnt.get("valu_lane_weighted_frac_of_chip"),
-                        basis="SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves / %d SIMDs (%s)"
-                              % (N_SIMD, ", ".join(cnt.get("source", []))))
-        else:  # no profile of this batch size: the flop model is all there is
-            roof.update(achieved=flops / dur_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                        frac=flops / dur_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                        basis="no PMC profile for this batch size: fp64 flop model / vector peak")
+            occ.update(frac_of_chip=cnt["valu_busy_frac_of_chip"],
+                       valu_busy_frac_per_wave=cnt.get("valu_busy_frac_per_wave"),
+                       simd_occupancy=cnt.get("simd_occupancy"),
+                       lane_weighted_frac=cnt.get("valu_lane_weighted_frac_of_chip"),
+                       basis="SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves / %d SIMDs (%s)"
+                             % (N_SIMD, ", ".join(cnt.get("source", []))))
+        roof["valu_issue"] = occ
     roof.update(traffic=traffic, kernel=kernel, kernel_ms=kernel_ms,
                 hbm={"measured_bytes_per_launch": traffic,
                      "measured_GBps": traffic / dur_s / 1e9 if traffic else None,
@@ -407,6 +430,13 @@ def cartpole_roofline(B, iters, kernel_ms, chunked):
                             "frac": flops / dur_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                             "flop_model": "problem-iterations x (90 kflop backward + 15 kflop per rollout)"})
     if cnt:
+        # the PMC passes are a stored profile of one build: say which, and whether this run still matches it
+        prof_ms = cnt.get("kernel_avg_ms")
+        stale = bool(prof_ms) and abs(kernel_ms - prof_ms) > 0.05 * prof_ms
+        roof["profile"] = {"kernel_avg_ms": prof_ms, "git_head": cnt.get("git_head"),
+                           "stale": stale,
+                           "note": "traffic, hbm.measured_* and valu_issue come from this stored rocprofv3 profile; "
+                                   "stale = its kernel time differs from this run's by more than 5 %"}
         roof["counters"] = cnt
     return roof
 

@@ -46,7 +46,17 @@ def keep_library_rows(path_in, path_out):
         csv.writer(fh, quoting=csv.QUOTE_MINIMAL).writerows(keep)
 
 
-entry = {"workload": workload, "batch": batch, "kernel": kernel_key, "source": []}
+import subprocess  # noqa: E402
+
+try:
+    head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                          check=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "ilqr_amd", "include"],
+                                capture_output=True, text=True, check=True).stdout.strip())
+except Exception:
+    head, dirty = None, None
+entry = {"workload": workload, "batch": batch, "kernel": kernel_key, "git_head": head, "sources_modified": dirty,
+         "source": []}
 stats = os.path.join(src, "stats", "stats_kernel_stats.csv")
 shutil.copy(stats, os.path.join(dst, prefix + "_kernel_stats.csv"))
 entry["source"].append("profiles/%s_kernel_stats.csv" % prefix)
