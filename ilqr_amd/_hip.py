@@ -29,6 +29,7 @@ class ModelC(C.Structure):
         ("dt", C.c_double), ("mc", C.c_double), ("mp", C.c_double), ("l", C.c_double), ("g", C.c_double),
         ("Q", _dp), ("R", _dp), ("Q_terminal", _dp), ("x_goal", _dp), ("u_goal", _dp),
         ("lower", _dp), ("upper", _dp),
+        ("goal_stride_x", C.c_int64), ("goal_stride_u", C.c_int64),
     ]
 
 
@@ -38,6 +39,7 @@ class LargeModelC(C.Structure):
         ("dt", C.c_double), ("sig_c", C.c_double),
         ("A", _vp), ("B", _vp), ("W", _vp), ("Q", _vp), ("R", _vp), ("Q_terminal", _vp),
         ("x_goal", _vp), ("u_goal", _vp), ("lower", _vp), ("upper", _vp),
+        ("goal_stride_x", C.c_int64), ("goal_stride_u", C.c_int64),
     ]
 
 
@@ -108,6 +110,20 @@ def _host(a, shape):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))
 
 
+def _ndim(a):
+    return a.dim() if hasattr(a, "dim") else np.ndim(a)
+
+
+def _dev64(a, device=None):
+    """A contiguous fp64 tensor on the GPU holding ``a`` (numpy array or tensor on any device)."""
+    import torch
+    if not torch.is_tensor(a):
+        a = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))
+    if device is None:
+        device = a.device if a.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return a.to(device=device, dtype=torch.float64).contiguous()
+
+
 class Model:
     """Host description of the problem family (model + cost + bounds)."""
 
@@ -115,13 +131,18 @@ class Model:
                  dt=0.05, mc=1.0, mp=0.1, l=1.0, g=9.8, n=5, m=1, model=MODEL_CARTPOLE, control_limit=True,
                  x_path=None, u_path=None):
         """QRCost: x_goal [n], u_goal [m] (host).  PathQRCost: x_path [T+1, n], u_path [T, m] as
-        fp64 device tensors (kept alive by this object); x_goal / u_goal are then ignored."""
+        fp64 device tensors (kept alive by this object); x_goal / u_goal are then ignored.
+        One goal or one path PER PROBLEM: x_goal [B, n] and u_goal [B, m], or x_path [B, T+1, n] and
+        u_path [B, T, m] (numpy or torch; copied to the GPU): problem b of every solve with this model
+        tracks row b."""
         self.n, self.m, self.T = int(n), int(m), int(T)
         self.Q = _host(Q, (n, n))
         self.R = _host(R, (m, m))
         self.Qt = self.Q if Q_terminal is None else _host(Q_terminal, (n, n))
-        self.x_goal = _host(np.zeros(n) if x_goal is None else x_goal, (n,))
-        self.u_goal = _host(np.zeros(m) if u_goal is None else u_goal, (m,))
+        self.batch_goals = None  # number of problems the per-problem goals are for
+        per_problem_goal = x_path is None and x_goal is not None and _ndim(x_goal) == 2
+        self.x_goal = _host(np.zeros(n) if (x_goal is None or per_problem_goal) else x_goal, (n,))
+        self.u_goal = _host(np.zeros(m) if (u_goal is None or per_problem_goal) else u_goal, (m,))
         self.lower = _host(lower, (m,))
         self.upper = _host(upper, (m,))
         c = ModelC()
@@ -135,14 +156,54 @@ class Model:
             import torch
             if u_path is None:
                 raise ValueError("PathQRCost needs both x_path and u_path")
-            self.x_path = _req(x_path, torch.float64)
-            self.u_path = _req(u_path, torch.float64)
-            if tuple(self.x_path.shape) != (T + 1, n) or tuple(self.u_path.shape) != (T, m):
-                raise ValueError("x_path must be [%d, %d] and u_path [%d, %d]" % (T + 1, n, T, m))
+            if _ndim(x_path) == 3:  # one path per problem
+                self.x_path, self.u_path = _dev64(x_path), _dev64(u_path)
+                Bg = self.x_path.shape[0]
+                if tuple(self.x_path.shape) != (Bg, T + 1, n) or tuple(self.u_path.shape) != (Bg, T, m):
+                    raise ValueError("per-problem paths must be x_path [B, %d, %d] and u_path [B, %d, %d]"
+                                     % (T + 1, n, T, m))
+                self.batch_goals = int(Bg)
+                c.goal_stride_x, c.goal_stride_u = (T + 1) * n, T * m
+            else:
+                self.x_path = _req(x_path, torch.float64)
+                self.u_path = _req(u_path, torch.float64)
+                if tuple(self.x_path.shape) != (T + 1, n) or tuple(self.u_path.shape) != (T, m):
+                    raise ValueError("x_path must be [%d, %d] and u_path [%d, %d]" % (T + 1, n, T, m))
             c.cost_kind = COST_PATH_QR
             c.x_goal = C.cast(C.c_void_p(self.x_path.data_ptr()), _dp)
             c.u_goal = C.cast(C.c_void_p(self.u_path.data_ptr()), _dp)
+        elif per_problem_goal:  # one QRCost goal per problem
+            self.x_goals = _dev64(x_goal)
+            Bg = self.x_goals.shape[0]
+            self.u_goals = _dev64(np.zeros((Bg, m)) if u_goal is None else u_goal)
+            if tuple(self.x_goals.shape) != (Bg, n) or tuple(self.u_goals.shape) != (Bg, m):
+                raise ValueError("per-problem goals must be x_goal [B, %d] and u_goal [B, %d]" % (n, m))
+            self.batch_goals = int(Bg)
+            c.goal_stride_x, c.goal_stride_u = n, m
+            c.x_goal = C.cast(C.c_void_p(self.x_goals.data_ptr()), _dp)
+            c.u_goal = C.cast(C.c_void_p(self.u_goals.data_ptr()), _dp)
         self.c = c
+
+    def subset(self, idx):
+        """The model for the sub-batch ``idx`` (device index tensor) of the problems it was built for: the same
+        object unless every problem has its own goal or path, else a copy with those gathered."""
+        if self.batch_goals is None:
+            return self
+        import copy
+        other = copy.copy(self)
+        c = ModelC()
+        C.memmove(C.byref(c), C.byref(self.c), C.sizeof(ModelC))
+        if self.c.cost_kind == COST_PATH_QR:
+            other.x_path, other.u_path = self.x_path[idx].contiguous(), self.u_path[idx].contiguous()
+            gx, gu = other.x_path, other.u_path
+        else:
+            other.x_goals, other.u_goals = self.x_goals[idx].contiguous(), self.u_goals[idx].contiguous()
+            gx, gu = other.x_goals, other.u_goals
+        other.batch_goals = int(gx.shape[0])
+        c.x_goal = C.cast(C.c_void_p(gx.data_ptr()), _dp)
+        c.u_goal = C.cast(C.c_void_p(gu.data_ptr()), _dp)
+        other.c = c
+        return other
 
 
 class Opts:
@@ -300,6 +361,7 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
     """
     import torch
     B = x0.shape[0]
+    _check_goal_batch(M, B)
     dev = x0.device
     T, n, m = M.T, M.n, M.m
     x0 = _req(x0.reshape(B, n), torch.float64)
@@ -351,6 +413,7 @@ def solve_static(M, O, x0, us_init, delta, k, K, out, trace=None):
     iters, status.  ``trace``: None or a dict of [max_iter, B] tensors keyed as TRACE_FIELDS."""
     import torch
     B = x0.shape[0]
+    _check_goal_batch(M, B)
     f64, i32 = torch.float64, torch.int32
     tr_c = None
     if trace is not None:
@@ -372,6 +435,7 @@ def solve_chunked(M, O, x0, us_init, chunk, delta=None, k=None, K=None, workspac
     (xs, us, J, mu, iters, status)."""
     import torch
     B, dev = x0.shape[0], x0.device
+    _check_goal_batch(M, B)
     T, n, m = M.T, M.n, M.m
     f64 = torch.float64
     x0 = _req(x0.reshape(B, n), f64)
@@ -464,7 +528,8 @@ class LargeModel:
 
     def __init__(self, T, A, B, W, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
                  dt=0.05, sig_c=2.0, device=None, x_path=None, u_path=None):
-        """x_path [T+1, 32], u_path [T, 8]: the goals of a PathQRCost instead of x_goal / u_goal."""
+        """x_path [T+1, 32], u_path [T, 8]: the goals of a PathQRCost instead of x_goal / u_goal.
+        One goal or path per problem: x_goal [B, 32], u_goal [B, 8] or x_path [B, T+1, 32], u_path [B, T, 8]."""
         import torch
         n, m = 32, 8
         self.n, self.m, self.T = n, m, int(T)
@@ -472,11 +537,13 @@ class LargeModel:
 
         def up(a, shape):
             return torch.tensor(_host(a, shape), device=dev)
+        self.batch_goals = None
+        per_problem_goal = x_path is None and x_goal is not None and _ndim(x_goal) == 2
         self.t = dict(
             A=up(A, (n, n)), B=up(B, (n, m)), W=up(W, (n, n)), Q=up(Q, (n, n)), R=up(R, (m, m)),
             Q_terminal=up(Q if Q_terminal is None else Q_terminal, (n, n)),
-            x_goal=up(np.zeros(n) if x_goal is None else x_goal, (n,)),
-            u_goal=up(np.zeros(m) if u_goal is None else u_goal, (m,)),
+            x_goal=up(np.zeros(n) if (x_goal is None or per_problem_goal) else x_goal, (n,)),
+            u_goal=up(np.zeros(m) if (u_goal is None or per_problem_goal) else u_goal, (m,)),
             lower=up(lower, (m,)), upper=up(upper, (m,)))
         c = LargeModelC()
         c.n, c.m, c.T, c.dt, c.sig_c = n, m, int(T), dt, sig_c
@@ -484,12 +551,51 @@ class LargeModel:
         if x_path is not None or u_path is not None:
             if x_path is None or u_path is None:
                 raise ValueError("PathQRCost needs both x_path and u_path")
-            self.t["x_goal"] = up(x_path, (int(T) + 1, n))
-            self.t["u_goal"] = up(u_path, (int(T), m))
+            if _ndim(x_path) == 3:  # one path per problem
+                self.t["x_goal"], self.t["u_goal"] = _dev64(x_path, dev), _dev64(u_path, dev)
+                Bg = self.t["x_goal"].shape[0]
+                if tuple(self.t["x_goal"].shape) != (Bg, int(T) + 1, n) or tuple(self.t["u_goal"].shape) != (Bg, int(T), m):
+                    raise ValueError("per-problem paths must be x_path [B, T+1, 32] and u_path [B, T, 8]")
+                self.batch_goals = int(Bg)
+                c.goal_stride_x, c.goal_stride_u = (int(T) + 1) * n, int(T) * m
+            else:
+                self.t["x_goal"] = up(x_path, (int(T) + 1, n))
+                self.t["u_goal"] = up(u_path, (int(T), m))
             c.cost_kind = COST_PATH_QR
+        elif per_problem_goal:
+            self.t["x_goal"] = _dev64(x_goal, dev)
+            Bg = self.t["x_goal"].shape[0]
+            self.t["u_goal"] = _dev64(np.zeros((Bg, m)) if u_goal is None else u_goal, dev)
+            if tuple(self.t["x_goal"].shape) != (Bg, n) or tuple(self.t["u_goal"].shape) != (Bg, m):
+                raise ValueError("per-problem goals must be x_goal [B, 32] and u_goal [B, 8]")
+            self.batch_goals = int(Bg)
+            c.goal_stride_x, c.goal_stride_u = n, m
         for name, t in self.t.items():
             setattr(c, name, t.data_ptr())
         self.c = c
+
+    def subset(self, idx):
+        """The model for the sub-batch ``idx`` (device index tensor) of the problems it was built for: the same
+        object unless every problem has its own goal, else a copy with those goals gathered."""
+        if self.batch_goals is None:
+            return self
+        import copy
+        other = copy.copy(self)
+        other.t = dict(self.t)
+        other.t["x_goal"] = self.t["x_goal"][idx].contiguous()
+        other.t["u_goal"] = self.t["u_goal"][idx].contiguous()
+        other.batch_goals = int(other.t["x_goal"].shape[0])
+        c = LargeModelC()
+        C.memmove(C.byref(c), C.byref(self.c), C.sizeof(LargeModelC))
+        c.x_goal, c.u_goal = other.t["x_goal"].data_ptr(), other.t["u_goal"].data_ptr()
+        other.c = c
+        return other
+
+
+def _check_goal_batch(M, B):
+    if getattr(M, "batch_goals", None) is not None and M.batch_goals != B:
+        raise ValueError("the model carries goals for %d problems, the batch has %d (Model.subset(idx) gives the "
+                         "model of a sub-batch)" % (M.batch_goals, B))
 
 
 def large_rollout_cost(M, x0, us):
@@ -552,6 +658,7 @@ def large_forward_ls(M, alphas, xs, us, k, K, store_idx=-1):
 def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=None, mu=None, dJ=None):
     import torch
     B, dev = x0.shape[0], x0.device
+    _check_goal_batch(M, B)
     T, n, m = M.T, M.n, M.m
     delta = torch.full((B,), 2.0, dtype=torch.float64, device=dev) if delta is None else delta
     k = torch.zeros((B, T, m), dtype=torch.float64, device=dev) if k is None else k

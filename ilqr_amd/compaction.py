@@ -75,7 +75,8 @@ def solve_compacting(solve_fn, M, opts_kw, max_iter, x0, us_init, delta=None, k=
             status = res["status"]
         else:
             d_i, k_i, K_i, mu_i, dJ_i = delta[idx], k[idx], K[idx], mu[idx], dJ[:, idx].contiguous()
-            res = solve_fn(M, opts[n_it], x0[idx], us[idx], delta=d_i, k=k_i, K=K_i, mu=mu_i, trace=trace, workspace=ws,
+            M_i = M.subset(idx) if hasattr(M, "subset") else M  # (per-problem goals follow their problems)
+            res = solve_fn(M_i, opts[n_it], x0[idx], us[idx], delta=d_i, k=k_i, K=K_i, mu=mu_i, trace=trace, workspace=ws,
                            dJ=dJ_i)
             delta[idx], k[idx], K[idx], mu[idx], dJ[:, idx] = d_i, k_i, K_i, mu_i, dJ_i
             xs[idx], us[idx], J[idx] = res["xs"], res["us"], res["J"]

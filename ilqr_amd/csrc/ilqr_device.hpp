@@ -56,6 +56,12 @@ struct QRCostP {      // QRCost, ilqr/ilqr_cost.py:490-530, m = 1
     // batch; device arrays [(T+1)*5] and [T], null for QRCost
     const double* x_path;
     const double* u_path;
+    // Per-problem goals (PathQR evaluator only): the goals travel in the solve's workspace like the trajectories
+    // (rows of a batch-minor array, see PathQR::bind); goal_t_x / goal_t_u = rows per time step (5 and 1 for
+    // per-problem paths, 0 for per-problem goals that do not depend on the step); vscale = 0.5 gives the values
+    // QRCost's factor (ilqr_cost.py:547, :553), 1.0 is PathQRCost's (:695, :701).
+    int goal_t_x, goal_t_u;
+    double vscale;
 };
 
 struct QPOptsP { // ilqr_core.py:154-155
@@ -251,6 +257,8 @@ struct DenseQR {
     __device__ __forceinline__ explicit DenseQR(const QRCostP& c) : C(c) {}
     __device__ __forceinline__ void at(int) const {}          // the goal does not depend on the step
     __device__ __forceinline__ void at_terminal(int) const {}
+    __device__ __forceinline__ void bind(const double*, const double*, int64_t) const {} // ... nor on the problem
+    __device__ __forceinline__ void column(int64_t) const {}
 
     __device__ __forceinline__ double quad(const double (&v)[NX], const double* M) const
     {
@@ -330,6 +338,8 @@ struct DiagQR {
     }
     __device__ __forceinline__ void at(int) const {}
     __device__ __forceinline__ void at_terminal(int) const {}
+    __device__ __forceinline__ void bind(const double*, const double*, int64_t) const {}
+    __device__ __forceinline__ void column(int64_t) const {}
     __device__ __forceinline__ double quad(const double (&v)[NX], const double (&d)[NX]) const
     {
         // the dense chain with every off-diagonal product dropped: column j of
@@ -383,20 +393,41 @@ struct DiagQR {
 
 // PathQRCost (ilqr/ilqr_cost.py:635-770): the goals are x_path[i], u_path[i], and the value
 // has NO 1/2 (:695, :701) while the gradients and Hessians are those of QRCost.  at(i) /
-// at_terminal(N) select the step before any evaluation (uniform loads: the path is shared
-// by all problems of the batch).
+// at_terminal(N) select the step before any evaluation.
+// The same evaluator serves goals that differ from problem to problem (every problem of the batch its own
+// QRCost goal or its own PathQRCost path, as B separate solver objects of the reference would have): bind()
+// hands it the goal rows of the wavefront's workspace tile, column() selects the problem whose trajectory is
+// being evaluated (not always the lane's own: the cooperative line search rolls out other lanes' problems),
+// and C.vscale restores QRCost's 1/2 on the values.  Without bind() the path is the batch's shared one
+// (uniform loads).
 struct PathQR {
     const QRCostP& C;
     mutable double xg[NX], ug;
-    __device__ __forceinline__ explicit PathQR(const QRCostP& c) : C(c)
+    mutable const double *gx, *gu; // null: shared path
+    mutable int64_t gld, col;
+    __device__ __forceinline__ explicit PathQR(const QRCostP& c) : C(c), gx(nullptr), gu(nullptr), gld(0), col(0)
     {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             xg[i] = 0.0;
         ug = 0.0;
     }
+    __device__ __forceinline__ void bind(const double* goal_x, const double* goal_u, int64_t ld) const
+    {
+        gx = goal_x;
+        gu = goal_u;
+        gld = ld;
+    }
+    __device__ __forceinline__ void column(int64_t b) const { col = b; }
     __device__ __forceinline__ void at(int t) const
     {
+        if (gx != nullptr) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                xg[i] = gx[((int64_t)t * C.goal_t_x + i) * gld + col];
+            ug = gu[(int64_t)t * C.goal_t_u * gld + col];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             xg[i] = C.x_path[t * NX + i];
@@ -404,6 +435,12 @@ struct PathQR {
     }
     __device__ __forceinline__ void at_terminal(int T) const
     {
+        if (gx != nullptr) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                xg[i] = gx[((int64_t)T * C.goal_t_x + i) * gld + col];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i)
             xg[i] = C.x_path[T * NX + i];
@@ -432,13 +469,13 @@ struct PathQR {
         double xd[NX];
         diff(x, xd);
         double ud = u - ug;
-        return quad(xd, C.Q) + (ud * C.R) * ud;
+        return quad(xd, C.Q) * C.vscale + ((ud * C.R) * ud) * C.vscale; // (x * 1.0 is x: PathQRCost's bits)
     }
     __device__ __forceinline__ double l_terminal(const double (&x)[NX]) const
     {
         double xd[NX];
         diff(x, xd);
-        return quad(xd, C.Qt);
+        return quad(xd, C.Qt) * C.vscale;
     }
     __device__ __forceinline__ void lx_with(const double* QQ, const double (&x)[NX], double (&out)[NX]) const
     {

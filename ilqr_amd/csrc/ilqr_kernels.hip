@@ -112,12 +112,15 @@ __global__ __launch_bounds__(256) void k_unpack(const double* __restrict__ srcA,
 // The four conversions on either side of a solve in one launch each (eight small launches cost a short
 // solve -- a closed-loop re-solve of 15 steps -- a sixth of its time).  Rows [y0[i], y0[i+1]) of the grid's
 // y dimension belong to job i.
+constexpr int PACK_JOBS = 6;
 struct PackJobs {
-    const double* src[4];
-    double* dst[4];
-    int64_t R[4];  // rows of the source, [B, R]
-    int64_t Rd[4]; // rows per tile of the wave-tiled destination (>= R: the rows land at the top of the tile)
-    unsigned y0[5];
+    const double* src[PACK_JOBS];
+    double* dst[PACK_JOBS];
+    int64_t R[PACK_JOBS];  // rows of the source, [B, R] ...
+    int64_t S[PACK_JOBS];  // ... whose rows are S doubles apart (S >= R)
+    int64_t Rd[PACK_JOBS]; // rows per tile of the wave-tiled destination (>= R: the rows land at the top of the tile)
+    unsigned y0[PACK_JOBS + 1];
+    int n;              // jobs in use
     const int64_t* idx; // not null: problem b of the launch is row idx[b] of the source arrays
 };
 __global__ __launch_bounds__(256) void k_pack_jobs(PackJobs Jb, int64_t B)
@@ -125,18 +128,19 @@ __global__ __launch_bounds__(256) void k_pack_jobs(PackJobs Jb, int64_t B)
     __shared__ double tile[64][65];
     int job = 0;
 #pragma unroll
-    for (int i = 1; i < 4; ++i)
-        job += blockIdx.y >= Jb.y0[i] ? 1 : 0;
+    for (int i = 1; i < PACK_JOBS; ++i)
+        job += (i < Jb.n && blockIdx.y >= Jb.y0[i]) ? 1 : 0;
     const double* __restrict__ src = Jb.src[0];
     double* __restrict__ dst = Jb.dst[0];
-    int64_t R = Jb.R[0], Rd = Jb.Rd[0];
+    int64_t R = Jb.R[0], Rd = Jb.Rd[0], S = Jb.S[0];
     unsigned y0 = Jb.y0[0];
 #pragma unroll
-    for (int i = 1; i < 4; ++i)
+    for (int i = 1; i < PACK_JOBS; ++i)
         if (job == i) {
             src = Jb.src[i];
             dst = Jb.dst[i];
             R = Jb.R[i];
+            S = Jb.S[i];
             Rd = Jb.Rd[i];
             y0 = Jb.y0[i];
         }
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k_pack_jobs(PackJobs Jb, int64_t B)
         double v = 0.0;
         if (b < B && r < R) {
             int64_t row = Jb.idx != nullptr ? Jb.idx[b] : b;
-            v = src[row * R + r];
+            v = src[row * S + r];
         }
         tile[j][tx] = v;
     }
@@ -323,6 +327,7 @@ __device__ __forceinline__ int backward_sweep(const CartpoleC& P, const Cost& C,
                                               BwAcc& S, int& stopped_at, int32_t* qp_result_bm,
                                               int32_t* free_bm)
 {
+    C.column(b); // (the cost's goal may belong to the problem)
     double xnext[NX];
     load5(xs, ld, (int64_t)T * NX, b, xnext);
     C.at_terminal(T);
@@ -546,6 +551,7 @@ __device__ __forceinline__ double forward_rollout(const CartpoleC& P, const Cost
                                                   double* __restrict__ xs_new,
                                                   double* __restrict__ us_new)
 {
+    C.column(b); // (the cost's goal may belong to the problem)
     // The operands of a step (old x, u, k, K: 12 numbers) are loaded TWO steps ahead: with one
     // wave per SIMD the bytes in flight are what sets the achieved bandwidth of a large batch.
     struct Ops {
@@ -723,6 +729,7 @@ __device__ __forceinline__ double forward_rollout_master(const CartpoleC& P, con
                                                          const double* __restrict__ K, double alpha,
                                                          double* __restrict__ xs_new, double* __restrict__ us_new)
 {
+    C.column(b); // (the cost's goal may belong to the problem)
     struct Ops {
         double xo[NX], Kr[NX], u, kk;
     };
@@ -823,6 +830,7 @@ __device__ __forceinline__ int pair_master_sweep(const Cost& C, const QPOptsP& Q
                                                  double* __restrict__ k, BwAcc& S, int& stopped_at,
                                                  const CartpoleC& P, const double* __restrict__ xs)
 {
+    C.column(b); // (the cost's goal may belong to the problem)
     S.dJ1 = 0.0;
     S.dJ2 = 0.0;
     S.qp_iter = S.qp_backtrack = S.n_clamped = 0;
@@ -1062,6 +1070,7 @@ __device__ __forceinline__ void pair_helper_sweep(const CartpoleC& P, const Cost
                                                   PairX& X, int lane, bool act, const double* __restrict__ xs,
                                                   const double* __restrict__ us, double mu, double* __restrict__ K)
 {
+    C.column(b); // (the cost's goal may belong to the problem)
     BwAcc S;
     double xnext[NX];
     load5(xs, ld, (int64_t)T * NX, b, xnext);
@@ -1336,6 +1345,9 @@ struct SolveBuffers {       // batch-minor workspace, two copies of everything t
     double* K[2];           // [T*5, ld]
     int32_t* sel_traj;      // [B] which copy holds the final trajectory
     int32_t* sel_gain;      // [B] which copy holds the final gains
+    const double* goal_x;   // per-problem goals: [goal_rows_x, ld] and [goal_rows_u, ld], or null (shared goals)
+    const double* goal_u;
+    int64_t goal_rows_x, goal_rows_u;
 };
 
 // Line-search candidates evaluated cooperatively by a wave in one pass.
@@ -1429,6 +1441,9 @@ __global__ __launch_bounds__(256, 1) void k_solve(CartpoleP mp, QRCostP Cp, Solv
     const int64_t bq = valid ? b : ((wave_global * lpw) & 63);
     CartpoleC P = cartpole_consts(mp);
     Cost C(Cp);
+    if (W.goal_x != nullptr) // every problem has its own goal or path: rows of this wavefront's tile
+        C.bind(W.goal_x + tile * W.goal_rows_x * 64, W.goal_u + tile * W.goal_rows_u * 64, ld);
+    C.column(b);
     QPOptsP QO = qp_opts_in_vgprs(O.qp);
     if constexpr (PAIR) {
         if ((threadIdx.x >> 6) == 1) { // the helper: one backward sweep per command of the master
@@ -1955,7 +1970,25 @@ int check_model(const ilqr_model* m)
         return ILQR_ERR_ARG;
     if (m->cost_kind == ILQR_COST_PATH_QR && (!m->x_goal || !m->u_goal)) // the paths are mandatory
         return ILQR_ERR_ARG;
+    if ((m->goal_stride_x != 0) != (m->goal_stride_u != 0))
+        return ILQR_ERR_ARG;
+    if (m->goal_stride_x != 0) { // one goal or path per problem, device arrays
+        const bool path = m->cost_kind == ILQR_COST_PATH_QR;
+        if (!m->x_goal || !m->u_goal || m->goal_stride_x < (path ? ((int64_t)m->T + 1) * 5 : 5) ||
+            m->goal_stride_u < (path ? (int64_t)m->T : 1))
+            return ILQR_ERR_ARG;
+    }
     return ILQR_OK;
+}
+
+inline bool per_problem_goals(const ilqr_model* m) { return m->goal_stride_x != 0; }
+// the stage entry points evaluate shared goals only
+inline int check_stage_model(const ilqr_model* m)
+{
+    int rc = check_model(m);
+    if (rc == ILQR_OK && per_problem_goals(m))
+        rc = ILQR_ERR_UNSUPPORTED;
+    return rc;
 }
 
 void fill_model(const ilqr_model* m, CartpoleP& mp, QRCostP& C, BoundsP& bd)
@@ -1975,7 +2008,19 @@ void fill_model(const ilqr_model* m, CartpoleP& mp, QRCostP& C, BoundsP& bd)
         }
     C.R = m->R[0];
     C.RR = m->R[0] + m->R[0];
-    if (m->cost_kind == ILQR_COST_PATH_QR) { // device arrays, read by the kernels
+    C.goal_t_x = C.goal_t_u = 0;
+    C.vscale = 1.0;
+    if (per_problem_goals(m)) { // device arrays, packed into the solve's workspace; the path evaluator reads them there
+        const bool path = m->cost_kind == ILQR_COST_PATH_QR;
+        for (int a = 0; a < 5; ++a)
+            C.xg[a] = 0.0;
+        C.ug = 0.0;
+        C.x_path = m->x_goal; // (marks the evaluator; the kernels do not read these two pointers)
+        C.u_path = m->u_goal;
+        C.goal_t_x = path ? 5 : 0;
+        C.goal_t_u = path ? 1 : 0;
+        C.vscale = path ? 1.0 : 0.5; // QRCost values carry the 1/2 (ilqr_cost.py:547, :553)
+    } else if (m->cost_kind == ILQR_COST_PATH_QR) { // device arrays, read by the kernels
         for (int a = 0; a < 5; ++a)
             C.xg[a] = 0.0;
         C.ug = 0.0;
@@ -2073,7 +2118,7 @@ inline dim3 tile_grid(int64_t B, int64_t R) { return dim3((unsigned)((B + 63) / 
 
 extern "C" {
 
-int ilqr_version(void) { return 101; }
+int ilqr_version(void) { return 102; }
 
 const char* ilqr_status_string(int s)
 {
@@ -2109,7 +2154,7 @@ int ilqr_unpack_bm(const double* src, double* dst, int64_t B, int64_t R, int64_t
 int ilqr_rollout_cost_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* x0,
                          const double* us, double* xs, double* J, void* stream)
 {
-    int rc = check_model(model);
+    int rc = check_stage_model(model);
     if (rc != ILQR_OK)
         return rc;
     if (!x0 || !us || !xs || !J || B < 1 || ld < B)
@@ -2133,7 +2178,7 @@ int ilqr_rollout_cost_bm(const ilqr_model* model, int64_t B, int64_t ld, const d
 int ilqr_deriv_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* xs, const double* us,
                   const ilqr_deriv_bm_t* out, void* stream)
 {
-    int rc = check_model(model);
+    int rc = check_stage_model(model);
     if (rc != ILQR_OK)
         return rc;
     if (!xs || !us || !out || B < 1 || ld < B || !out->fx || !out->fu || !out->lx || !out->lu ||
@@ -2157,7 +2202,7 @@ int ilqr_backward_bm(const ilqr_model* model, const ilqr_opts* opts, int64_t B, 
                      const ilqr_deriv_bm_t* deriv, double* k, double* K, double* dJ, int32_t* info,
                      int32_t* qp_result_bm, int32_t* free_bm, void* stream)
 {
-    int rc = check_model(model);
+    int rc = check_stage_model(model);
     if (rc != ILQR_OK)
         return rc;
     if (!us || !mu || !k || !K || !dJ || !info || B < 1 || ld < B || (deriv == nullptr && !xs))
@@ -2220,7 +2265,7 @@ int ilqr_forward_ls_bm(const ilqr_model* model, int64_t B, int64_t ld, int32_t n
                        const double* alphas, const double* xs, const double* us, const double* k,
                        const double* K, double* J_new, double* xs_new, double* us_new, void* stream)
 {
-    int rc = check_model(model);
+    int rc = check_stage_model(model);
     if (rc != ILQR_OK)
         return rc;
     if (!alphas || n_alpha < 1 || n_alpha > 32 || !xs || !us || !k || !K || !J_new || B < 1 || ld < B ||
@@ -2255,12 +2300,22 @@ int ilqr_forward_ls_bm(const ilqr_model* model, int64_t B, int64_t ld, int32_t n
     return hip_status(hipGetLastError());
 }
 
+// rows of the per-problem goals in the solve's workspace (0: shared goals)
+static int64_t goal_rows_x(const ilqr_model* m)
+{
+    return !per_problem_goals(m) ? 0 : (m->cost_kind == ILQR_COST_PATH_QR ? ((int64_t)m->T + 1) * 5 : 5);
+}
+static int64_t goal_rows_u(const ilqr_model* m)
+{
+    return !per_problem_goals(m) ? 0 : (m->cost_kind == ILQR_COST_PATH_QR ? (int64_t)m->T : 1);
+}
+
 size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B)
 {
     if (check_model(model) != ILQR_OK || B < 1)
         return 0;
     int64_t ld = ilqr_bm_ld(B), T = model->T;
-    int64_t rows = 2 * ((T + 1) * 5 + T + T + T * 5);
+    int64_t rows = 2 * ((T + 1) * 5 + T + T + T * 5) + goal_rows_x(model) + goal_rows_u(model);
     return (size_t)rows * ld * sizeof(double) + 2 * (size_t)ld * sizeof(int32_t);
 }
 
@@ -2268,9 +2323,9 @@ size_t ilqr_solve_workspace_bytes(const ilqr_model* model, int64_t B)
 // of each belongs to problem b of this launch; idx == nullptr: row b), with the per-problem SCALARS (delta, J,
 // mu, iters, status, trace) compact, [B].  The chunked solve continues its running problems this way without
 // staging copies of their trajectories and gains.
-static // Compute units of the current device, looked up once per device and process (the launch-shape rules below are
+// Compute units of the current device, looked up once per device and process (the launch-shape rules below are
 // on the path of every solve, closed-loop re-solves of ~0.1 ms included).
-int device_cu_count()
+static int device_cu_count()
 {
     static std::atomic<int> cached[64];
     int dev = 0;
@@ -2285,7 +2340,7 @@ int device_cu_count()
     return v;
 }
 
-int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+static int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
                                  const double* us_init, double* delta, double* k, double* K, double* xs,
                                  double* us, double* J, double* mu, int32_t* iters, int32_t* status,
                                  const ilqr_trace* trace, void* workspace, size_t workspace_bytes, void* stream,
@@ -2317,25 +2372,39 @@ int solve_batched_indexed(const ilqr_model* model, const ilqr_opts* opts, int64_
         W.k[c] = p;  p += T * ld;
         W.K[c] = p;  p += T * 5 * ld;
     }
+    W.goal_rows_x = goal_rows_x(model);
+    W.goal_rows_u = goal_rows_u(model);
+    double* const goal_x = p; p += W.goal_rows_x * ld;
+    double* const goal_u = p; p += W.goal_rows_u * ld;
+    W.goal_x = per_problem_goals(model) ? goal_x : nullptr;
+    W.goal_u = per_problem_goals(model) ? goal_u : nullptr;
     W.sel_traj = reinterpret_cast<int32_t*>(p);
     W.sel_gain = W.sel_traj + ld;
 
-    // into the wave-tiled workspace, one launch: x0 goes to rows 0..4 of the (T+1)*5-row state array of each tile
+    // into the wave-tiled workspace, one launch: x0 goes to rows 0..4 of the (T+1)*5-row state array of each tile;
+    // goals that differ from problem to problem travel the same way
     {
         PackJobs Jb;
-        const double* srcs[4] = {x0, us_init, k, K};
-        double* dsts[4] = {W.xs[0], W.us[0], W.k[0], W.K[0]};
-        const int64_t rows[4] = {5, T, T, T * 5}, rows_dst[4] = {(T + 1) * 5, T, T, T * 5};
+        const int nj = per_problem_goals(model) ? 6 : 4;
+        const double* srcs[PACK_JOBS] = {x0, us_init, k, K, model->x_goal, model->u_goal};
+        double* dsts[PACK_JOBS] = {W.xs[0], W.us[0], W.k[0], W.K[0], goal_x, goal_u};
+        const int64_t rows[PACK_JOBS] = {5, T, T, T * 5, W.goal_rows_x, W.goal_rows_u};
+        const int64_t strides[PACK_JOBS] = {5, T, T, T * 5, model->goal_stride_x, model->goal_stride_u};
+        const int64_t rows_dst[PACK_JOBS] = {(T + 1) * 5, T, T, T * 5, W.goal_rows_x, W.goal_rows_u};
         unsigned y = 0;
-        for (int i = 0; i < 4; ++i) {
-            Jb.src[i] = srcs[i];
-            Jb.dst[i] = dsts[i];
-            Jb.R[i] = rows[i];
-            Jb.Rd[i] = rows_dst[i];
+        for (int i = 0; i < PACK_JOBS; ++i) {
+            const bool on = i < nj;
+            Jb.src[i] = on ? srcs[i] : nullptr;
+            Jb.dst[i] = on ? dsts[i] : nullptr;
+            Jb.R[i] = on ? rows[i] : 0;
+            Jb.S[i] = on ? strides[i] : 0;
+            Jb.Rd[i] = on ? rows_dst[i] : 0;
             Jb.y0[i] = y;
-            y += (unsigned)((rows[i] + 63) / 64);
+            if (on)
+                y += (unsigned)((rows[i] + 63) / 64);
         }
-        Jb.y0[4] = y;
+        Jb.y0[PACK_JOBS] = y;
+        Jb.n = nj;
         Jb.idx = idx;
         hipLaunchKernelGGL(k_pack_jobs, dim3((unsigned)((B + 63) / 64), y), dim3(256), 0, st, Jb, B);
     }

@@ -130,7 +130,17 @@ struct LargeP { // kernel arguments: the model, all device pointers
     double dt, sig_c;
     int T;
     int path; // PathQRCost: xg [T+1][n], ug [T][m] hold the goal of every time step, values carry no 1/2
+    int64_t gsx, gsu; // doubles between the goals (or paths) of consecutive problems; 0: shared by the batch
 };
+
+// the model as problem b sees it: its own goal or path if the batch has one per problem
+__device__ __forceinline__ LargeP for_problem(const LargeP& P, int64_t b)
+{
+    LargeP Q = P;
+    Q.xg = P.xg + b * P.gsx;
+    Q.ug = P.ug + b * P.gsu;
+    return Q;
+}
 
 struct LQPOpts {
     int max_iter;
@@ -749,9 +759,9 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
     fu[0][0] = load_n(&M.fu[0][0], LM + 1, LN, LM, 0, 0, L);
     fu[1][0] = load_n(&M.fu[0][0], LM + 1, LN, LM, 1, 0, L);
     RR[0][0] = load_n(&M.RR[0][0], LM, LM, LM, 0, 0, L);
-    xg[0][0] = load_v(M.xg, LN, 0, L);
-    xg[1][0] = load_v(M.xg, LN, 1, L);
-    ug[0][0] = load_v(M.ug, LM, 0, L);
+    xg[0][0] = load_v(P.xg, LN, 0, L);
+    xg[1][0] = load_v(P.xg, LN, 1, L);
+    ug[0][0] = load_v(P.ug, LM, 0, L);
     if (PATH) { // the terminal goal
         xg[0][0] = load_v(P.xg + (size_t)T * LN, LN, 0, L);
         xg[1][0] = load_v(P.xg + (size_t)T * LN, LN, 1, L);
@@ -1182,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_large_rollout_cost(LargeP P, int64_t B,
     if (b >= B)
         return;
     WaveMem& S = M.wv[threadIdx.x >> 6];
-    large_forward<true, PATH>(P, S, nullptr, us + b * P.T * LM, nullptr, nullptr, x0 + b * LN, 0.0, 0,
+    large_forward<true, PATH>(for_problem(P, b), S, nullptr, us + b * P.T * LM, nullptr, nullptr, x0 + b * LN, 0.0, 0,
                         xs + b * (P.T + 1) * LN, nullptr);
     if ((threadIdx.x & 63) == 0)
         J[b] = S.J[0];
@@ -1201,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_large_backward(LargeP P, LQPOpts QO, in
         return;
     WaveMem& S = M.wv[threadIdx.x >> 6];
     BwOut o;
-    large_backward<PATH>(P, QO, M, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
+    large_backward<PATH>(for_problem(P, b), QO, M, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
                    K + b * P.T * LM * LN, o, qp_result ? qp_result + b * P.T : nullptr,
                    free_mask ? free_mask + b * P.T * LM : nullptr);
     if ((threadIdx.x & 63) == 0) {
@@ -1238,7 +1248,7 @@ __global__ __launch_bounds__(256) void k_large_forward_ls(LargeP P, LAlphas al, 
         int j = pass * LA + L.c;
         double a = j < n_alpha ? al.a[j < 32 ? j : 0] : 0.0;
         int sc = (store_idx >= pass * LA && store_idx < (pass + 1) * LA) ? store_idx - pass * LA : -1;
-        large_forward<false, PATH>(P, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, k + b * P.T * LM,
+        large_forward<false, PATH>(for_problem(P, b), S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, k + b * P.T * LM,
                              K + b * P.T * LM * LN, xs + b * (P.T + 1) * LN, a, sc,
                              xs_new ? xs_new + b * (P.T + 1) * LN : nullptr, us_new ? us_new + b * P.T * LM : nullptr);
         if (lane < LA && pass * LA + lane < n_alpha)
@@ -1253,13 +1263,14 @@ struct LSolveBuf {
 
 // iLQR.update_u (ilqr_core.py:241-399) for problem b, run by one wavefront.
 template <bool PATH>
-__device__ __forceinline__ void large_solve_one(const LargeP& P, const LSolveOpts& O, BlockMem& M, WaveMem& S,
+__device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSolveOpts& O, BlockMem& M, WaveMem& S,
                                                 const int64_t b, const int64_t B, const double* x0,
                                                 const double* us_init, double* delta_io, double* k0, double* K0,
                                                 double* xs0, double* us0, const LSolveBuf& W, double* J_out,
                                                 double* mu_out, int32_t* iters_out, int32_t* status_out,
                                                 const ilqr_trace& tr)
 {
+    const LargeP P = for_problem(P_batch, b);
     const int T = P.T;
     const LaneId L = lane_id();
     const int lane = threadIdx.x & 63;
@@ -1478,14 +1489,14 @@ __global__ __launch_bounds__(256) void k_large_deriv(LargeP P, int64_t B, const 
             double sq = 1.0 + z * z;
             s_g[s][i] = P.sig_c * (1.0 / (sq * sqrt(sq)));
             // l_x[i] = sum_a x_diff[a] (Q + Q^T)[a][i]   (ilqr_cost.py:555-569)
-            const double* xg = PATH ? P.xg + (int64_t)t * LN : P.xg;
+            const double* xg = P.xg + b * P.gsx + (PATH ? (int64_t)t * LN : 0);
             double acc = (s_x[s][0] - xg[0]) * s_QQ[0][i];
 #pragma unroll 8
             for (int a = 1; a < LN; ++a)
                 acc = fma(s_x[s][a] - xg[a], s_QQ[a][i], acc);
             o.lx[(b * T + t) * LN + i] = acc;
             if (i < LM) { // l_u[i] = sum_a u_diff[a] (R + R^T)[a][i]   (:571-587)
-                const double* ug = PATH ? P.ug + (int64_t)t * LM : P.ug;
+                const double* ug = P.ug + b * P.gsu + (PATH ? (int64_t)t * LM : 0);
                 const double* u = us + (b * T + t) * LM;
                 double au = (u[0] - ug[0]) * s_RR[0][i];
 #pragma unroll
@@ -1494,7 +1505,7 @@ __global__ __launch_bounds__(256) void k_large_deriv(LargeP P, int64_t B, const 
                 o.lu[(b * T + t) * LM + i] = au;
             }
         } else if (t == T) { // terminal l_x, l_xx (ilqr_core.py:120-121), Q_terminal read from memory
-            const double* xg = PATH ? P.xg + (int64_t)T * LN : P.xg;
+            const double* xg = P.xg + b * P.gsx + (PATH ? (int64_t)T * LN : 0);
             double acc = (s_x[s][0] - xg[0]) * (P.Qt[0 * LN + i] + P.Qt[i * LN + 0]);
             for (int a = 1; a < LN; ++a)
                 acc = fma(s_x[s][a] - xg[a], P.Qt[a * LN + i] + P.Qt[i * LN + a], acc);
@@ -1532,6 +1543,13 @@ int large_check(const ilqr_large_model* m)
         return ILQR_ERR_ARG;
     if (m->cost_kind != ILQR_COST_QR && m->cost_kind != ILQR_COST_PATH_QR)
         return ILQR_ERR_UNSUPPORTED;
+    if ((m->goal_stride_x != 0) != (m->goal_stride_u != 0))
+        return ILQR_ERR_ARG;
+    if (m->goal_stride_x != 0) { // one goal or path per problem
+        const bool path = m->cost_kind == ILQR_COST_PATH_QR;
+        if (m->goal_stride_x < (path ? ((int64_t)m->T + 1) * LN : LN) || m->goal_stride_u < (path ? (int64_t)m->T * LM : LM))
+            return ILQR_ERR_ARG;
+    }
     return ILQR_OK;
 }
 
@@ -1552,6 +1570,8 @@ LargeP large_fill(const ilqr_large_model* m)
     P.sig_c = m->sig_c;
     P.T = m->T;
     P.path = m->cost_kind == ILQR_COST_PATH_QR ? 1 : 0;
+    P.gsx = m->goal_stride_x;
+    P.gsu = m->goal_stride_u;
     return P;
 }
 

@@ -60,8 +60,8 @@ class iLQR(BaseTrajOptimizer):
                 "run inside a kernel" % type(sys_dynamics).__name__)
         if not isinstance(cost_func, (QRCost, PathQRCost)):
             raise NotImplementedError("only QRCost and PathQRCost have a device implementation")
-        if isinstance(cost_func, PathQRCost) and cost_func.x_path.shape[0] != int(time_steps) + 1:
-            raise ValueError("x_path holds %d states, the horizon needs %d" % (cost_func.x_path.shape[0],
+        if isinstance(cost_func, PathQRCost) and cost_func.x_path.shape[-2] != int(time_steps) + 1:
+            raise ValueError("x_path holds %d states, the horizon needs %d" % (cost_func.x_path.shape[-2],
                                                                              int(time_steps) + 1))
         if control_limit is not True:
             # In the reference this branch keeps the positive-sign warm-start gains, predicts a
@@ -286,7 +286,8 @@ class iLQR(BaseTrajOptimizer):
                 idx = torch.tensor(np.nonzero(active_h)[0], device=dev)
                 d_i, k_i, K_i, mu_i = delta[idx].contiguous(), k[idx].contiguous(), K[idx].contiguous(), mu[idx].contiguous()
                 dJ_i = dJ[:, idx].contiguous()
-                res = self._solve(M, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
+                M_i = M.subset(idx) if hasattr(M, "subset") else M  # (per-problem goals follow their problems)
+                res = self._solve(M_i, O, x0_d[idx].contiguous(), us[idx].contiguous(), delta=d_i, k=k_i, K=K_i, mu=mu_i,
                                   trace=True, dJ=dJ_i)
                 delta[idx], k[idx], K[idx], mu[idx], dJ[:, idx] = d_i, k_i, K_i, mu_i, dJ_i
                 xs[idx], us[idx], J[idx] = res["xs"], res["us"], res["J"]

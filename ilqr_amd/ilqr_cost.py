@@ -44,7 +44,11 @@ class QRCost(Cost):
     """Quadratic Regulator Instantaneous Cost (ilqr/ilqr_cost.py:486-632).
 
     As in the reference the VALUE carries a factor 1/2 that the derivatives do not
-    (l = x'Qx/2 + u'Ru/2 but l_x = x'(Q+Q'), l_xx = Q+Q', l_uu = R+R')."""
+    (l = x'Qx/2 + u'Ru/2 but l_x = x'(Q+Q'), l_xx = Q+Q', l_uu = R+R').
+
+    Batched extension: ``x_goal`` [B, n] (and ``u_goal`` [B, m]) gives every problem of a batched solve its own
+    goal, as B solver objects of the reference, each with its own QRCost, would have; the host-side methods
+    below then evaluate problem 0's goal unless given the goal row explicitly through ``for_problem(b)``."""
 
     def __init__(self, Q, R, Q_terminal=None, x_goal=None, u_goal=None):
         self.Q = np.array(Q, dtype=np.float64)
@@ -52,19 +56,33 @@ class QRCost(Cost):
         self.Q_terminal = self.Q if Q_terminal is None else np.array(Q_terminal, dtype=np.float64)
         self.x_goal = np.zeros(self.Q.shape[0]) if x_goal is None else np.array(x_goal, dtype=np.float64)
         self.u_goal = np.zeros(self.R.shape[0]) if u_goal is None else np.array(u_goal, dtype=np.float64)
+        if self.x_goal.ndim == 2 and self.u_goal.ndim == 1:  # one state goal per problem, one control goal for all
+            self.u_goal = np.broadcast_to(self.u_goal, (self.x_goal.shape[0], self.u_goal.shape[0])).copy()
+        elif self.u_goal.ndim == 2 and self.x_goal.ndim == 1:
+            self.x_goal = np.broadcast_to(self.x_goal, (self.u_goal.shape[0], self.x_goal.shape[0])).copy()
 
         assert self.Q.shape == self.Q_terminal.shape, "Q & Q_terminal mismatch"
         assert self.Q.shape[0] == self.Q.shape[1], "Q must be square"
         assert self.R.shape[0] == self.R.shape[1], "R must be square"
-        assert self.Q.shape[0] == self.x_goal.shape[0], "Q & x_goal mismatch"
-        assert self.R.shape[0] == self.u_goal.shape[0], "R & u_goal mismatch"
+        assert self.Q.shape[0] == self.x_goal.shape[-1], "Q & x_goal mismatch"
+        assert self.R.shape[0] == self.u_goal.shape[-1], "R & u_goal mismatch"
+        assert self.x_goal.ndim == self.u_goal.ndim and self.x_goal.shape[:-1] == self.u_goal.shape[:-1], \
+            "x_goal & u_goal batch mismatch"
 
         self._Q_plus_Q_T = self.Q + self.Q.T
         self._R_plus_R_T = self.R + self.R.T
         self._Q_plus_Q_T_terminal = self.Q_terminal + self.Q_terminal.T
         super().__init__()
 
+    def for_problem(self, b):
+        """The QRCost of problem ``b`` of a batch with per-problem goals (a plain single-goal cost)."""
+        if self.x_goal.ndim == 1:
+            return self
+        return QRCost(self.Q, self.R, self.Q_terminal, self.x_goal[b], self.u_goal[b])
+
     def l(self, x, u, i, terminal=False):
+        if self.x_goal.ndim == 2:
+            return self.for_problem(0).l(x, u, i, terminal)
         Q = self.Q_terminal if terminal else self.Q
         x_diff = x - self.x_goal
         squared_x_cost = x_diff.T.dot(Q).dot(x_diff) * 0.5
@@ -74,10 +92,14 @@ class QRCost(Cost):
         return squared_x_cost + u_diff.T.dot(self.R).dot(u_diff) * 0.5
 
     def l_x(self, x, u, i, terminal=False):
+        if self.x_goal.ndim == 2:
+            return self.for_problem(0).l_x(x, u, i, terminal)
         Q_plus_Q_T = self._Q_plus_Q_T_terminal if terminal else self._Q_plus_Q_T
         return (x - self.x_goal).T.dot(Q_plus_Q_T)
 
     def l_u(self, x, u, i, terminal=False):
+        if self.x_goal.ndim == 2:
+            return self.for_problem(0).l_u(x, u, i, terminal)
         if terminal:
             return np.zeros_like(self.u_goal)
         return (u - self.u_goal).T.dot(self._R_plus_R_T)
@@ -99,8 +121,10 @@ class PathQRCost(Cost):
     (ilqr/ilqr_cost.py:635-770): goals x_path[i], u_path[i] indexed by the time step.
 
     As in the reference the VALUE has no factor 1/2 here (l = x'Qx + u'Ru, :695-701)
-    while the derivatives are those of QRCost (l_x = x'(Q+Q'), ...).  One path is
-    shared by every problem of a batch.
+    while the derivatives are those of QRCost (l_x = x'(Q+Q'), ...).  ``x_path`` [N+1, n] is one
+    path shared by every problem of a batch; ``x_path`` [B, N+1, n] (with ``u_path`` [B, N, m]) gives every
+    problem of a batched solve its own path, as B solver objects of the reference would have
+    (``for_problem(b)`` is problem b's plain cost for host-side evaluation).
 
     ``u_path=None``: the reference crashes there (``np.zeros(path_length - 1,
     action_size)``, :663, is a TypeError); the zeros it meant to build are used."""
@@ -112,20 +136,22 @@ class PathQRCost(Cost):
 
         state_size = self.Q.shape[0]
         action_size = self.R.shape[0]
-        path_length = self.x_path.shape[0]
+        path_length = self.x_path.shape[-2]
 
         self.Q_terminal = self.Q if Q_terminal is None else np.array(Q_terminal, dtype=np.float64)
         if u_path is None:
-            self.u_path = np.zeros((path_length - 1, action_size))
+            self.u_path = np.zeros(self.x_path.shape[:-2] + (path_length - 1, action_size))
         else:
             self.u_path = np.array(u_path, dtype=np.float64)
 
         assert self.Q.shape == self.Q_terminal.shape, "Q & Q_terminal mismatch"
         assert self.Q.shape[0] == self.Q.shape[1], "Q must be square"
         assert self.R.shape[0] == self.R.shape[1], "R must be square"
-        assert state_size == self.x_path.shape[1], "Q & x_path mismatch"
-        assert action_size == self.u_path.shape[1], "R & u_path mismatch"
-        assert path_length == self.u_path.shape[0] + 1, "x_path must be 1 longer than u_path"
+        assert state_size == self.x_path.shape[-1], "Q & x_path mismatch"
+        assert action_size == self.u_path.shape[-1], "R & u_path mismatch"
+        assert path_length == self.u_path.shape[-2] + 1, "x_path must be 1 longer than u_path"
+        assert self.x_path.ndim == self.u_path.ndim and self.x_path.shape[:-2] == self.u_path.shape[:-2], \
+            "x_path & u_path batch mismatch"
 
         self._Q_plus_Q_T = self.Q + self.Q.T
         self._R_plus_R_T = self.R + self.R.T
@@ -156,7 +182,15 @@ class PathQRCost(Cost):
                 entry[3] = u_h.copy()
         return entry[0], entry[1]
 
+    def for_problem(self, b):
+        """The PathQRCost of problem ``b`` of a batch with per-problem paths."""
+        if self.x_path.ndim == 2:
+            return self
+        return PathQRCost(self.Q, self.R, self.x_path[b], self.u_path[b], self.Q_terminal)
+
     def l(self, x, u, i, terminal=False):
+        if self.x_path.ndim == 3:
+            return self.for_problem(0).l(x, u, i, terminal)
         Q = self.Q_terminal if terminal else self.Q
         x_diff = x - self.x_path[i]
         squared_x_cost = x_diff.T.dot(Q).dot(x_diff)

@@ -61,6 +61,15 @@ typedef struct ilqr_model {
     const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] row-major */
     const double *x_goal, *u_goal;    /* QR: host [n], [m] (NULL = zeros); PATH_QR: device [(T+1)*n], [T*m] */
     const double *lower, *upper;      /* dynamics.lower_bound / upper_bound, [m] */
+    /* Per-problem goals.  In the reference every problem is its own solver object with its own cost
+     * (ilqr_cost.py:490-530, :639-770), so B independent calls may each track their own goal or path.
+     * goal_stride_x = goal_stride_u = 0: the goals above, shared by the batch.  Non-zero (both): x_goal and
+     * u_goal are DEVICE arrays holding one goal (QR: n resp. m numbers) or one path (PATH_QR: (T+1)*n resp. T*m
+     * numbers) per problem, problem b's at x_goal + b * goal_stride_x and u_goal + b * goal_stride_u (strides
+     * in doubles, at least the size of one goal / path).  The solve entry points accept them (the single-launch,
+     * chunked and static ones); the stage entry points (*_bm) return ILQR_ERR_UNSUPPORTED.
+     * (ilqr_version() >= 102; zero-initialise the struct so that callers built before keep shared goals.) */
+    int64_t goal_stride_x, goal_stride_u;
 } ilqr_model;
 
 /* update_u keyword arguments (ilqr_core.py:241), the solver constants of
@@ -271,6 +280,10 @@ typedef struct ilqr_large_model {
     const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] */
     const double *x_goal, *u_goal;    /* [n], [m] (or the paths, see cost_kind) */
     const double *lower, *upper;      /* [m] */
+    /* 0, 0: the goals above are shared by the batch.  Non-zero (both): problem b has its own goal (or path) at
+     * x_goal + b * goal_stride_x and u_goal + b * goal_stride_u (doubles); accepted by every ilqr_large_* entry
+     * point.  See ilqr_model for the counterpart in the reference. */
+    int64_t goal_stride_x, goal_stride_u;
 } ilqr_large_model;
 
 /* iLQR._dynamics_rollout + _trajectory_cost (ilqr_core.py:69-83, :230-239):
