@@ -63,17 +63,23 @@ __host__ __device__ inline int64_t utile_rows(int64_t T) { return 2 * ((T + 1) *
 struct UCost { // QRCost (ilqr/ilqr_cost.py:490-530) or PathQRCost (:635-770), m = 1
     double Q[UN * UN], Qt[UN * UN], QQ[UN * UN], QQt[UN * UN];
     double R, RR, xg[UN], ug;
-    const double *x_path, *u_path; // PathQRCost: device arrays [T+1][n], [T]; goals by time step, value without 1/2
-    int path;
+    const double *x_path, *u_path; // device goals, or null (the goal is xg, ug): PathQRCost [T+1][n], [T] (goals by
+                                   // time step, value without 1/2) and / or one goal or path per problem
+    int path;                      // 1: the goals depend on the time step (PathQRCost)
+    int64_t gsx, gsu;              // doubles between the goals of consecutive problems (0: shared by the batch)
 };
-// goal of time step t (wave-uniform loads in the path mode)
-__device__ __forceinline__ void ugoal_x(const UCost& C, int t, double (&xg)[UN])
+// goal of problem gp at time step t (wave-uniform loads when the batch shares one path)
+__device__ __forceinline__ void ugoal_x(const UCost& C, int64_t gp, int t, double (&xg)[UN])
 {
+    const double* g = C.x_path != nullptr ? C.x_path + gp * C.gsx + (C.path ? (int64_t)t * UN : 0) : C.xg;
 #pragma unroll
     for (int i = 0; i < UN; ++i)
-        xg[i] = C.path ? C.x_path[(int64_t)t * UN + i] : C.xg[i];
+        xg[i] = g[i];
 }
-__device__ __forceinline__ double ugoal_u(const UCost& C, int t) { return C.path ? C.u_path[t] : C.ug; }
+__device__ __forceinline__ double ugoal_u(const UCost& C, int64_t gp, int t)
+{
+    return C.u_path != nullptr ? C.u_path[gp * C.gsu + (C.path ? t : 0)] : C.ug;
+}
 struct UBounds {
     double lo, hi;
 };
@@ -105,15 +111,15 @@ __device__ __forceinline__ double uquad(const double (&v)[UN], const double* M)
     }
     return tot;
 }
-__device__ __forceinline__ double ucost_l(const UCost& C, const double (&x)[UN], double u, int t)
+__device__ __forceinline__ double ucost_l(const UCost& C, const double (&x)[UN], double u, int64_t gp, int t)
 {
     double xd[UN], xg[UN];
-    ugoal_x(C, t, xg);
+    ugoal_x(C, gp, t, xg);
 #pragma unroll
     for (int i = 0; i < UN; ++i)
         xd[i] = x[i] - xg[i];
     double sx = uquad(xd, C.Q);
-    double ud = u - ugoal_u(C, t);
+    double ud = u - ugoal_u(C, gp, t);
     double su = (ud * C.R) * ud;
     if (!C.path) { // QRCost.l carries the 1/2 (ilqr_cost.py:547-552), PathQRCost.l does not (:695-701)
         sx = sx * 0.5;
@@ -121,21 +127,21 @@ __device__ __forceinline__ double ucost_l(const UCost& C, const double (&x)[UN],
     }
     return sx + su;
 }
-__device__ __forceinline__ double ucost_lT(const UCost& C, const double (&x)[UN], int T)
+__device__ __forceinline__ double ucost_lT(const UCost& C, const double (&x)[UN], int64_t gp, int T)
 {
     double xd[UN], xg[UN];
-    ugoal_x(C, T, xg);
+    ugoal_x(C, gp, T, xg);
 #pragma unroll
     for (int i = 0; i < UN; ++i)
         xd[i] = x[i] - xg[i];
     double sx = uquad(xd, C.Qt);
     return C.path ? sx : sx * 0.5;
 }
-__device__ __forceinline__ void ucost_lx(const double* QQ, const UCost& C, const double (&x)[UN], int t,
+__device__ __forceinline__ void ucost_lx(const double* QQ, const UCost& C, const double (&x)[UN], int64_t gp, int t,
                                          double (&out)[UN])
 {
     double xd[UN], xg[UN];
-    ugoal_x(C, t, xg);
+    ugoal_x(C, gp, t, xg);
 #pragma unroll
     for (int i = 0; i < UN; ++i)
         xd[i] = x[i] - xg[i];
@@ -157,13 +163,13 @@ struct UAcc {
 
 // One step of _backward_pass (ilqr_core.py:127-176) with the dense _compute_Q_terms (:179-228).
 __device__ __forceinline__ int ubw_step(const UParams& P, const UCost& C, const QPOptsP& QO, const double* tab,
-                                        const double (&x)[UN], double u, int t, double mu, double lower, double upper,
-                                        UAcc& S, double& k_out, double (&K_out)[UN])
+                                        const double (&x)[UN], double u, int64_t gp, int t, double mu, double lower,
+                                        double upper, UAcc& S, double& k_out, double (&K_out)[UN])
 {
     double fx[UN * UN], fu[UN], lx[UN];
     ilqr_user_jac(P.p, x, u, fx, fu);
-    ucost_lx(C.QQ, C, x, t, lx);
-    double lu = (u - ugoal_u(C, t)) * C.RR;
+    ucost_lx(C.QQ, C, x, gp, t, lx);
+    double lu = (u - ugoal_u(C, gp, t)) * C.RR;
     const double* Vx = S.Vx;
     const double* Vxx = S.Vxx;
     double Qx[UN], Qxx[UN * UN], Qux[UN], M1[UN * UN], M2[UN];
@@ -273,12 +279,13 @@ __device__ __forceinline__ int ubw_step(const UParams& P, const UCost& C, const 
 
 // One backward sweep; gains of the steps it does not reach are zero (np.zeros_like, :118-119).
 __device__ int ubackward(const UParams& P, const UCost& C, const QPOptsP& QO, const double* tab, const UBounds& bd,
-                         int T, int64_t ld, int64_t b, const double* xs, const double* us, double mu, double* k,
-                         double* K, UAcc& S, int& stopped_at)
+                         int T, int64_t ld, int64_t b, int64_t gp0, const double* xs, const double* us, double mu,
+                         double* k, double* K, UAcc& S, int& stopped_at)
 {
+    const int64_t gp = gp0 + b; // the problem in column b of the tile: its goal may be its own
     double xT[UN];
     uload(xs, ld, (int64_t)T * UN, b, xT);
-    ucost_lx(C.QQt, C, xT, T, S.Vx);
+    ucost_lx(C.QQt, C, xT, gp, T, S.Vx);
 #pragma unroll
     for (int i = 0; i < UN * UN; ++i)
         S.Vxx[i] = C.QQt[i];
@@ -296,7 +303,7 @@ __device__ int ubackward(const UParams& P, const UCost& C, const QPOptsP& QO, co
             double x[UN], kt, Kt[UN];
             uload(xs, ld, (int64_t)i * UN, b, x);
             double u = us[(int64_t)i * ld + b];
-            int r = ubw_step(P, C, QO, tab, x, u, i, mu, bd.lo, bd.hi, S, kt, Kt);
+            int r = ubw_step(P, C, QO, tab, x, u, gp, i, mu, bd.lo, bd.hi, S, kt, Kt);
             if (r == BW_OK) {
                 kk = kt;
 #pragma unroll
@@ -315,10 +322,11 @@ __device__ int ubackward(const UParams& P, const UCost& C, const QPOptsP& QO, co
 }
 
 // _forward_pass + _trajectory_cost (ilqr_core.py:85-107, :230-239); k == nullptr: plain rollout of us.
-__device__ double uforward(const UParams& P, const UCost& C, int T, int64_t ld, int64_t b, const double* xs,
-                           const double* us, const double* k, const double* K, double alpha, const double* x0,
-                           double* xs_new, double* us_new)
+__device__ double uforward(const UParams& P, const UCost& C, int T, int64_t ld, int64_t b, int64_t gp0,
+                           const double* xs, const double* us, const double* k, const double* K, double alpha,
+                           const double* x0, double* xs_new, double* us_new)
 {
+    const int64_t gp = gp0 + b;
     double xn[UN], xt[UN];
 #pragma unroll
     for (int i = 0; i < UN; ++i)
@@ -341,7 +349,7 @@ __device__ double uforward(const UParams& P, const UCost& C, int T, int64_t ld, 
             ustore(xs_new, ld, (int64_t)t * UN, b, xn);
             us_new[(int64_t)t * ld + b] = un;
         }
-        J = J + ucost_l(C, xn, un, t);
+        J = J + ucost_l(C, xn, un, gp, t);
         ilqr_user_f(P.p, xn, un, xt);
 #pragma unroll
         for (int a = 0; a < UN; ++a)
@@ -349,7 +357,7 @@ __device__ double uforward(const UParams& P, const UCost& C, int T, int64_t ld, 
     }
     if (xs_new != nullptr)
         ustore(xs_new, ld, (int64_t)T * UN, b, xn);
-    return J + ucost_lT(C, xn, T);
+    return J + ucost_lT(C, xn, gp, T);
 }
 
 // Workspace of one wavefront's 64 problems: rows of 64 doubles (lane = problem), two copies of
@@ -412,7 +420,8 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
     qp_fill_step_table(s_qp_tab, O.qp.step_dec); // ends with the workgroup barrier
     // problems per wavefront: the first O.lanes_per_wave columns of the wave's 64-column tile are in use
     const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
-    const int64_t b = tile * O.lanes_per_wave + lane;
+    const int64_t gp0 = tile * O.lanes_per_wave; // problem in column 0 of the tile
+    const int64_t b = gp0 + lane;
     const bool valid = lane < O.lanes_per_wave && b < B;
     const UWork W = utile(ws, tile, T);
     const int64_t ld = 64, bl = lane; // row stride and column inside the tile
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
         mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
         delta = delta_io[b];
         // initial rollout and cost (:269-271)
-        J = uforward(P, C, T, ld, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
+        J = uforward(P, C, T, ld, bl, gp0, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
     }
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
     if (valid && O.mu_from_array && O.dJ_carry != nullptr) { // a continued solve: the sums of its last backward pass
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
             // backward pass with the LinAlgError retry loop (:287-299)
             for (;;) {
                 int gnew = gcur ^ 1;
-                int rc = ubackward(P, C, QO, s_qp_tab, bd, T, ld, bl, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S,
+                int rc = ubackward(P, C, QO, s_qp_tab, bd, T, ld, bl, gp0, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S,
                                    stopped_at);
                 if (rc != BW_LINALG) {
                     gcur = gnew;
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
             // line search, alpha_0 (:301-313)
             if (O.n_alpha > 0) {
                 double alpha = s_alpha[0];
-                Jnew = uforward(P, C, T, ld, bl, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
+                Jnew = uforward(P, C, T, ld, bl, gp0, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
                 double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
                 if (expected <= 0.0) {
                     // reject the whole iteration
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
                     int fi = q / n_more, jj = 1 + q % n_more;
                     int64_t pb = s_lane[fi];
                     int pc = s_cur[fi], pg = s_gcur[fi];
-                    s_J[fi][jj] = uforward(P, C, T, ld, pb, XS(pc), US(pc), KF(pg), KG(pg), s_alpha[jj], XS(pc), nullptr,
+                    s_J[fi][jj] = uforward(P, C, T, ld, pb, gp0, XS(pc), US(pc), KF(pg), KG(pg), s_alpha[jj], XS(pc), nullptr,
                                            nullptr);
                 }
             }
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
             mask = __ballot(need);
         }
         if (redo) // the accepted candidate's states and controls (same arithmetic, same bits)
-            Jnew = uforward(P, C, T, ld, bl, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(cur), XS(nxt), US(nxt));
+            Jnew = uforward(P, C, T, ld, bl, gp0, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(cur), XS(nxt), US(nxt));
         if (running) {
             bool stop = false;
             int converged = 0;
@@ -616,11 +625,18 @@ __global__ __launch_bounds__(256, 1) void k_user_solve(UParams P, UCost C_arg, S
 
 struct GCost { // QRCost (ilqr/ilqr_cost.py:490-530) or PathQRCost (:635-770)
     double Q[UN * UN], Qt[UN * UN], R[UM * UM], xg[UN], ug[UM];
-    const double *x_path, *u_path; // PathQRCost: device arrays [T+1][n], [T][m]
+    const double *x_path, *u_path; // device goals or null (see UCost): [T+1][n], [T][m] per path
     int path;
+    int64_t gsx, gsu;
 };
-__device__ __forceinline__ const double* ggoal_x(const GCost& C, int t) { return C.path ? C.x_path + (int64_t)t * UN : C.xg; }
-__device__ __forceinline__ const double* ggoal_u(const GCost& C, int t) { return C.path ? C.u_path + (int64_t)t * UM : C.ug; }
+__device__ __forceinline__ const double* ggoal_x(const GCost& C, int64_t gp, int t)
+{
+    return C.x_path != nullptr ? C.x_path + gp * C.gsx + (C.path ? (int64_t)t * UN : 0) : C.xg;
+}
+__device__ __forceinline__ const double* ggoal_u(const GCost& C, int64_t gp, int t)
+{
+    return C.u_path != nullptr ? C.u_path + gp * C.gsu + (C.path ? (int64_t)t * UM : 0) : C.ug;
+}
 struct GBounds {
     double lo[UM], hi[UM];
 };
@@ -641,10 +657,10 @@ __device__ __forceinline__ void gstore(double* base, int64_t row0, int64_t b, co
 }
 
 // QRCost.l, ilqr_cost.py:532-553 (the value carries the 1/2 its gradients lack)
-__device__ inline double gcost_l(const GCost& C, const double* x, const double* u, int t, bool terminal)
+__device__ inline double gcost_l(const GCost& C, const double* x, const double* u, int64_t gp, int t, bool terminal)
 {
     double xd[UN], ud[UM];
-    const double* xg = ggoal_x(C, t);
+    const double* xg = ggoal_x(C, gp, t);
     for (int a = 0; a < UN; ++a)
         xd[a] = x[a] - xg[a];
     double sx = qpg_quad(UN, xd, terminal ? C.Qt : C.Q);
@@ -652,7 +668,7 @@ __device__ inline double gcost_l(const GCost& C, const double* x, const double* 
         sx = sx * 0.5;
     if (terminal)
         return sx;
-    const double* ug = ggoal_u(C, t);
+    const double* ug = ggoal_u(C, gp, t);
     for (int a = 0; a < UM; ++a)
         ud[a] = u[a] - ug[a];
     double su = qpg_quad(UM, ud, C.R);
@@ -661,10 +677,10 @@ __device__ inline double gcost_l(const GCost& C, const double* x, const double* 
     return sx + su;
 }
 // l_x = x_diff^T (Q + Q^T), ilqr_cost.py:555-569
-__device__ inline void gcost_lx(const GCost& C, const double* x, int t, bool terminal, double* out)
+__device__ inline void gcost_lx(const GCost& C, const double* x, int64_t gp, int t, bool terminal, double* out)
 {
     const double* Qm = terminal ? C.Qt : C.Q;
-    const double* xg = ggoal_x(C, t);
+    const double* xg = ggoal_x(C, gp, t);
     double xd[UN];
     for (int a = 0; a < UN; ++a)
         xd[a] = x[a] - xg[a];
@@ -684,7 +700,7 @@ struct GAcc {
 
 // One step of _backward_pass (ilqr_core.py:127-176) with _compute_Q_terms (:179-228).
 __device__ int gbw_step(const UParams& P, const GCost& C, const QPOptsP& QO, const GBounds& bd, const double* x,
-                        const double* u, int t, double mu, GAcc& S, double* ki, double* Ki)
+                        const double* u, int64_t gp, int t, double mu, GAcc& S, double* ki, double* Ki)
 {
     constexpr int n = UN, m = UM;
     double fx[n * n], fu[n * m], lx[n], lu[m];
@@ -692,10 +708,10 @@ __device__ int gbw_step(const UParams& P, const GCost& C, const QPOptsP& QO, con
     const double* Vx = S.Vx;
     const double* Vxx = S.Vxx;
     ilqr_user_jac(P.p, x, u, fx, fu);
-    gcost_lx(C, x, t, false, lx);
+    gcost_lx(C, x, gp, t, false, lx);
     {   // l_u = u_diff^T (R + R^T), ilqr_cost.py:571-587
         double ud[m];
-        const double* ug = ggoal_u(C, t);
+        const double* ug = ggoal_u(C, gp, t);
         for (int a = 0; a < m; ++a)
             ud[a] = u[a] - ug[a];
         for (int j = 0; j < m; ++j) {
@@ -843,11 +859,13 @@ __device__ int gbw_step(const UParams& P, const GCost& C, const QPOptsP& QO, con
 
 // One backward sweep; gains of the steps it does not reach are zero (np.zeros_like, :118-119).
 __device__ int gbackward(const UParams& P, const GCost& C, const QPOptsP& QO, const GBounds& bd, int T, int64_t b,
-                         const double* xs, const double* us, double mu, double* k, double* K, GAcc& S, int& stopped_at)
+                         int64_t gp0, const double* xs, const double* us, double mu, double* k, double* K, GAcc& S,
+                         int& stopped_at)
 {
+    const int64_t gp = gp0 + b; // the problem in column b of the tile: its goal may be its own
     double xT[UN];
     gload<UN>(xs, (int64_t)T * UN, b, xT);
-    gcost_lx(C, xT, T, true, S.Vx);
+    gcost_lx(C, xT, gp, T, true, S.Vx);
     for (int a = 0; a < UN; ++a)
         for (int c = 0; c < UN; ++c)
             S.Vxx[a * UN + c] = C.Qt[a * UN + c] + C.Qt[c * UN + a];
@@ -866,7 +884,7 @@ __device__ int gbackward(const UParams& P, const GCost& C, const QPOptsP& QO, co
             double x[UN], u[UM], kt[UM], Kt[UM * UN];
             gload<UN>(xs, (int64_t)i * UN, b, x);
             gload<UM>(us, (int64_t)i * UM, b, u);
-            int r = gbw_step(P, C, QO, bd, x, u, i, mu, S, kt, Kt);
+            int r = gbw_step(P, C, QO, bd, x, u, gp, i, mu, S, kt, Kt);
             if (r == BW_OK) {
                 for (int a = 0; a < UM; ++a)
                     ki[a] = kt[a];
@@ -885,10 +903,11 @@ __device__ int gbackward(const UParams& P, const GCost& C, const QPOptsP& QO, co
 }
 
 // _forward_pass + _trajectory_cost (ilqr_core.py:85-107, :230-239); k == nullptr: plain rollout of us.
-__device__ double gforward(const UParams& P, const GCost& C, int T, int64_t b, const double* xs, const double* us,
-                           const double* k, const double* K, double alpha, const double* x0, double* xs_new,
-                           double* us_new)
+__device__ double gforward(const UParams& P, const GCost& C, int T, int64_t b, int64_t gp0, const double* xs,
+                           const double* us, const double* k, const double* K, double alpha, const double* x0,
+                           double* xs_new, double* us_new)
 {
+    const int64_t gp = gp0 + b;
     double xn[UN], xt[UN];
     gload<UN>(x0, 0, b, xn);
     double J = 0.0;
@@ -913,14 +932,14 @@ __device__ double gforward(const UParams& P, const GCost& C, int T, int64_t b, c
             gstore<UN>(xs_new, (int64_t)t * UN, b, xn);
             gstore<UM>(us_new, (int64_t)t * UM, b, un);
         }
-        J = J + gcost_l(C, xn, un, t, false);
+        J = J + gcost_l(C, xn, un, gp, t, false);
         ilqr_user_f(P.p, xn, un, xt);
         for (int a = 0; a < UN; ++a)
             xn[a] = xt[a];
     }
     if (xs_new != nullptr)
         gstore<UN>(xs_new, (int64_t)T * UN, b, xn);
-    return J + gcost_l(C, xn, nullptr, T, true);
+    return J + gcost_l(C, xn, nullptr, gp, T, true);
 }
 
 struct UWork {
@@ -975,7 +994,8 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
     __syncthreads();
     // problems per wavefront: the first O.lanes_per_wave columns of the wave's 64-column tile are in use
     const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
-    const int64_t b = tile * O.lanes_per_wave + lane;
+    const int64_t gp0 = tile * O.lanes_per_wave; // problem in column 0 of the tile
+    const int64_t b = gp0 + lane;
     const bool valid = lane < O.lanes_per_wave && b < B;
     const UWork W = utile(ws, tile, T);
     const int64_t bl = lane;
@@ -1000,7 +1020,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
         mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
         delta = delta_io[b];
         // initial rollout and cost (:269-271)
-        J = gforward(P, C, T, bl, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
+        J = gforward(P, C, T, bl, gp0, nullptr, W.us0, nullptr, nullptr, 0.0, W.xs0, W.xs0, W.us0);
     }
     double dJ1 = 0.0, dJ2 = 0.0, actual = 0.0;
     if (valid && O.mu_from_array && O.dJ_carry != nullptr) { // a continued solve: the sums of its last backward pass
@@ -1024,7 +1044,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
             // backward pass with the LinAlgError retry loop (:287-299)
             for (;;) {
                 int gnew = gcur ^ 1;
-                int rc = gbackward(P, C, QO, bd, T, bl, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S, stopped_at);
+                int rc = gbackward(P, C, QO, bd, T, bl, gp0, XS(cur), US(cur), mu, KF(gnew), KG(gnew), S, stopped_at);
                 if (rc != BW_LINALG) {
                     gcur = gnew;
                     dJ1 = S.dJ1;
@@ -1039,7 +1059,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
             // line search, alpha_0 (:301-313)
             if (O.n_alpha > 0) {
                 double alpha = s_alpha[0];
-                Jnew = gforward(P, C, T, bl, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
+                Jnew = gforward(P, C, T, bl, gp0, XS(cur), US(cur), KF(gcur), KG(gcur), alpha, XS(cur), XS(nxt), US(nxt));
                 double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
                 if (expected <= 0.0) {
                     // reject the whole iteration
@@ -1076,7 +1096,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
                     int fi = q / n_more, jj = 1 + q % n_more;
                     int64_t pb = s_lane[fi];
                     int pc = s_cur[fi], pg = s_gcur[fi];
-                    s_J[fi][jj] = gforward(P, C, T, pb, XS(pc), US(pc), KF(pg), KG(pg), s_alpha[jj], XS(pc), nullptr, nullptr);
+                    s_J[fi][jj] = gforward(P, C, T, pb, gp0, XS(pc), US(pc), KF(pg), KG(pg), s_alpha[jj], XS(pc), nullptr, nullptr);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1102,7 +1122,7 @@ __global__ __launch_bounds__(256, 1) void k_user_solve_m(UParams P, GCost C_arg,
             mask = __ballot(need);
         }
         if (redo) // the accepted candidate's states and controls (same arithmetic, same bits)
-            Jnew = gforward(P, C, T, bl, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(cur), XS(nxt), US(nxt));
+            Jnew = gforward(P, C, T, bl, gp0, XS(cur), US(cur), KF(gcur), KG(gcur), s_alpha[j], XS(cur), XS(nxt), US(nxt));
         if (running) {
             bool stop = false;
             int converged = 0;
@@ -1184,6 +1204,13 @@ int ucheck(const ilqr_user_model* m)
         return ILQR_ERR_ARG;
     if (m->cost_kind != ILQR_COST_QR && m->cost_kind != ILQR_COST_PATH_QR)
         return ILQR_ERR_UNSUPPORTED;
+    if ((m->goal_stride_x != 0) != (m->goal_stride_u != 0))
+        return ILQR_ERR_ARG;
+    if (m->goal_stride_x != 0 &&
+        (!m->x_goal || !m->u_goal ||
+         m->goal_stride_x < (m->cost_kind == ILQR_COST_PATH_QR ? ((int64_t)m->T + 1) * UN : UN) ||
+         m->goal_stride_u < (m->cost_kind == ILQR_COST_PATH_QR ? (int64_t)m->T * UM : UM)))
+        return ILQR_ERR_ARG;
     if (m->cost_kind == ILQR_COST_PATH_QR && (!m->x_goal || !m->u_goal))
         return ILQR_ERR_ARG; // the paths are required (device arrays)
     return ILQR_OK;
@@ -1269,14 +1296,17 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
             C.QQ[a * UN + b] = model->Q[a * UN + b] + model->Q[b * UN + a];
             C.QQt[a * UN + b] = Qt[a * UN + b] + Qt[b * UN + a];
         }
-        C.xg[a] = (!path && model->x_goal) ? model->x_goal[a] : 0.0;
+        C.xg[a] = (!path && model->goal_stride_x == 0 && model->x_goal) ? model->x_goal[a] : 0.0;
     }
     C.R = model->R[0];
     C.RR = model->R[0] + model->R[0];
-    C.ug = (!path && model->u_goal) ? model->u_goal[0] : 0.0;
+    C.ug = (!path && model->goal_stride_x == 0 && model->u_goal) ? model->u_goal[0] : 0.0;
+    const bool dev_goals = path || model->goal_stride_x != 0;
     C.path = path ? 1 : 0;
-    C.x_path = path ? model->x_goal : nullptr;
-    C.u_path = path ? model->u_goal : nullptr;
+    C.x_path = dev_goals ? model->x_goal : nullptr;
+    C.u_path = dev_goals ? model->u_goal : nullptr;
+    C.gsx = model->goal_stride_x;
+    C.gsu = model->goal_stride_u;
     UBounds bd;
     bd.lo = model->lower[0];
     bd.hi = model->upper[0];
@@ -1288,14 +1318,17 @@ int ilqr_user_solve_batched(const ilqr_user_model* model, const ilqr_opts* opts,
     }
     for (int a = 0; a < UM * UM; ++a)
         C.R[a] = model->R[a];
+    const bool dev_goals = path || model->goal_stride_x != 0;
     for (int a = 0; a < UN; ++a)
-        C.xg[a] = (!path && model->x_goal) ? model->x_goal[a] : 0.0;
+        C.xg[a] = (!dev_goals && model->x_goal) ? model->x_goal[a] : 0.0;
     C.path = path ? 1 : 0;
-    C.x_path = path ? model->x_goal : nullptr;
-    C.u_path = path ? model->u_goal : nullptr;
+    C.x_path = dev_goals ? model->x_goal : nullptr;
+    C.u_path = dev_goals ? model->u_goal : nullptr;
+    C.gsx = model->goal_stride_x;
+    C.gsu = model->goal_stride_u;
     GBounds bd;
     for (int a = 0; a < UM; ++a) {
-        C.ug[a] = (!path && model->u_goal) ? model->u_goal[a] : 0.0;
+        C.ug[a] = (!dev_goals && model->u_goal) ? model->u_goal[a] : 0.0;
         bd.lo[a] = model->lower[a];
         bd.hi[a] = model->upper[a];
     }

@@ -30,7 +30,8 @@ class UserModelC(C.Structure):
     _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("n_params", C.c_int32),
                 ("cost_kind", C.c_int32), ("pad_", C.c_int32)] + \
                [(k, C.POINTER(C.c_double)) for k in ("params", "Q", "R", "Q_terminal", "x_goal", "u_goal", "lower",
-                                                     "upper")]
+                                                     "upper")] + \
+               [("goal_stride_x", C.c_int64), ("goal_stride_u", C.c_int64)]
 
 
 def library_path(name):
@@ -55,34 +56,75 @@ class UserModel(object):
     def __init__(self, lib, T, params, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
                  x_path=None, u_path=None):
         """QRCost: x_goal [n], u_goal [m] (host).  PathQRCost: x_path [T+1, n], u_path [T, m] as device
-        tensors (time-indexed goals shared by the batch; the value then carries no 1/2)."""
+        tensors (time-indexed goals shared by the batch; the value then carries no 1/2).
+        One goal or path per problem: x_goal [B, n], u_goal [B, m] or x_path [B, T+1, n], u_path [B, T, m]."""
         n, npar = C.c_int32(), C.c_int32()
         _hip.check(lib.ilqr_user_dims(C.byref(n), C.byref(npar)))
         m = int(lib.ilqr_user_controls())
         self.lib, self.n, self.m, self.T = lib, n.value, m, int(T)
         host = _hip._host
+        dp = C.POINTER(C.c_double)
+        self.batch_goals = None
+        per_problem_goal = x_path is None and x_goal is not None and _hip._ndim(x_goal) == 2
         self.a = dict(params=host(params, (npar.value,)), Q=host(Q, (self.n, self.n)), R=host(R, (m, m)),
                       Q_terminal=host(Q if Q_terminal is None else Q_terminal, (self.n, self.n)),
-                      x_goal=host(np.zeros(self.n) if x_goal is None else x_goal, (self.n,)),
-                      u_goal=host(np.zeros(m) if u_goal is None else u_goal, (m,)),
+                      x_goal=host(np.zeros(self.n) if (x_goal is None or per_problem_goal) else x_goal, (self.n,)),
+                      u_goal=host(np.zeros(m) if (u_goal is None or per_problem_goal) else u_goal, (m,)),
                       lower=host(lower, (m,)), upper=host(upper, (m,)))
         c = UserModelC()
         c.n, c.m, c.T, c.n_params = self.n, m, int(T), npar.value
         for k, v in self.a.items():
-            setattr(c, k, v.ctypes.data_as(C.POINTER(C.c_double)))
+            setattr(c, k, v.ctypes.data_as(dp))
         c.cost_kind = _hip.COST_QR
+        self.gx = self.gu = None  # device goals (paths and / or per-problem goals)
         if x_path is not None or u_path is not None:
             import torch
             if x_path is None or u_path is None:
                 raise ValueError("PathQRCost needs both x_path and u_path")
-            self.x_path = _hip._req(x_path, torch.float64)
-            self.u_path = _hip._req(u_path, torch.float64)
-            if tuple(self.x_path.shape) != (int(T) + 1, self.n) or tuple(self.u_path.shape) != (int(T), m):
-                raise ValueError("x_path must be [%d, %d] and u_path [%d, %d]" % (int(T) + 1, self.n, int(T), m))
+            if _hip._ndim(x_path) == 3:
+                self.gx, self.gu = _hip._dev64(x_path), _hip._dev64(u_path)
+                Bg = self.gx.shape[0]
+                if tuple(self.gx.shape) != (Bg, int(T) + 1, self.n) or tuple(self.gu.shape) != (Bg, int(T), m):
+                    raise ValueError("per-problem paths must be x_path [B, %d, %d] and u_path [B, %d, %d]"
+                                     % (int(T) + 1, self.n, int(T), m))
+                self.batch_goals = int(Bg)
+                c.goal_stride_x, c.goal_stride_u = (int(T) + 1) * self.n, int(T) * m
+            else:
+                self.gx = _hip._req(x_path, torch.float64)
+                self.gu = _hip._req(u_path, torch.float64)
+                if tuple(self.gx.shape) != (int(T) + 1, self.n) or tuple(self.gu.shape) != (int(T), m):
+                    raise ValueError("x_path must be [%d, %d] and u_path [%d, %d]" % (int(T) + 1, self.n, int(T), m))
             c.cost_kind = _hip.COST_PATH_QR
-            c.x_goal = C.cast(C.c_void_p(self.x_path.data_ptr()), C.POINTER(C.c_double))
-            c.u_goal = C.cast(C.c_void_p(self.u_path.data_ptr()), C.POINTER(C.c_double))
+        elif per_problem_goal:
+            self.gx = _hip._dev64(x_goal)
+            Bg = self.gx.shape[0]
+            self.gu = _hip._dev64(np.zeros((Bg, m)) if u_goal is None else u_goal)
+            if tuple(self.gx.shape) != (Bg, self.n) or tuple(self.gu.shape) != (Bg, m):
+                raise ValueError("per-problem goals must be x_goal [B, %d] and u_goal [B, %d]" % (self.n, m))
+            self.batch_goals = int(Bg)
+            c.goal_stride_x, c.goal_stride_u = self.n, m
+        if self.gx is not None:
+            c.x_goal = C.cast(C.c_void_p(self.gx.data_ptr()), dp)
+            c.u_goal = C.cast(C.c_void_p(self.gu.data_ptr()), dp)
+        self.x_path, self.u_path = self.gx, self.gu
         self.c = c
+
+    def subset(self, idx):
+        """The model for the sub-batch ``idx`` of the problems it was built for (per-problem goals gathered)."""
+        if self.batch_goals is None:
+            return self
+        import copy
+        other = copy.copy(self)
+        other.gx, other.gu = self.gx[idx].contiguous(), self.gu[idx].contiguous()
+        other.x_path, other.u_path = other.gx, other.gu
+        other.batch_goals = int(other.gx.shape[0])
+        c = UserModelC()
+        C.memmove(C.byref(c), C.byref(self.c), C.sizeof(UserModelC))
+        dp = C.POINTER(C.c_double)
+        c.x_goal = C.cast(C.c_void_p(other.gx.data_ptr()), dp)
+        c.u_goal = C.cast(C.c_void_p(other.gu.data_ptr()), dp)
+        other.c = c
+        return other
 
 
 def load(name):
@@ -101,6 +143,7 @@ def solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, workspace=
     """ilqr_user_solve_batched on reference-layout device tensors (same dict as _hip.solve)."""
     import torch
     B, dev = x0.shape[0], x0.device
+    _hip._check_goal_batch(M, B)
     T, n, m = M.T, M.n, M.m
     f64 = torch.float64
     delta = torch.full((B,), 2.0, dtype=f64, device=dev) if delta is None else delta

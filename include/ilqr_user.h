@@ -43,6 +43,10 @@ typedef struct ilqr_user_model {
     const double *Q, *R, *Q_terminal; /* [n*n], [m*m], [n*n] (Q_terminal NULL = Q) */
     const double *x_goal, *u_goal;    /* [n], [m] (NULL = zeros) */
     const double *lower, *upper;      /* [m] */
+    /* 0, 0: shared goals.  Non-zero (both): x_goal / u_goal are DEVICE arrays with one goal (QR) or one path
+     * (PATH_QR) per problem, problem b's at x_goal + b * goal_stride_x, u_goal + b * goal_stride_u (doubles).
+     * See ilqr_model in ilqr_hip.h. */
+    int64_t goal_stride_x, goal_stride_u;
 } ilqr_user_model;
 
 /* The dimensions the library was compiled for (states, parameters; controls). */

@@ -227,3 +227,37 @@ def test_large_state_path_with_goals_and_paths_per_problem(hip):
     idx = torch.tensor([1, 4, 13], device=DEV)
     part = hip.large_solve(Mp.subset(idx), hip.Opts(max_iter=n_it), dev(x0)[idx], dev(us0)[idx])
     assert eq(part["us"].cpu().numpy(), refp["us"][[1, 4, 13]])
+
+
+def test_user_models_with_goals_and_paths_per_problem(hip):
+    """The per-model libraries (one control: pendulum; two controls: planar rotor) with one goal, resp. one
+    path, per problem, against loops of single-problem oracle solves on the same model source; enough
+    iterations for searches past the first step size (evaluated by other lanes)."""
+    from ilqr_amd import user_model as um
+    from test_user_model_cpu import pendulum, pendulum_batch, rotor, rotor_batch
+    T, B, n_it = 30, 90, 25
+    Mo = pendulum(T)
+    x0, us0 = pendulum_batch(B, T, seed=81)
+    r = np.random.RandomState(82)
+    th = r.uniform(-0.6, 0.6, B)
+    xg = np.stack([np.sin(th), np.cos(th), np.zeros(B)], 1)
+    ug = r.uniform(-0.2, 0.2, (B, 1))
+    ref = oracle_loop(lambda b: co.user_model(Mo.user, Mo.user_params, T, Mo.Q, Mo.R, Mo.Qt, xg[b], ug[b], Mo.lower,
+                                              Mo.upper), x0, us0, n_it)
+    M = um.UserModel(um.load("pendulum_user"), T, Mo.user_params, Mo.Q, Mo.R, Mo.Qt, xg, ug, Mo.lower, Mo.upper)
+    compare(um.solve(M, hip.Opts(max_iter=n_it), dev(x0), dev(us0)), ref, "pendulum, goals")
+    idx = torch.tensor([0, 33, 89], device=DEV)
+    part = um.solve(M.subset(idx), hip.Opts(max_iter=n_it), dev(x0)[idx], dev(us0)[idx])
+    assert eq(part["us"].cpu().numpy(), ref["us"][[0, 33, 89]])
+
+    Mr = rotor(T)
+    x0, us0 = rotor_batch(B, T, seed=83)
+    xp = np.tile(np.asarray(Mr.x_goal)[None, None], (B, T + 1, 1))
+    xp[:, :, 0] += np.cumsum(r.uniform(-0.05, 0.05, (B, T + 1)), axis=1)
+    xp[:, :, 1] += r.uniform(-0.5, 0.5, (B, 1))
+    up = r.uniform(-0.1, 0.1, (B, T, 2))
+    refp = oracle_loop(lambda b: co.user_model(Mr.user, Mr.user_params, T, Mr.Q, Mr.R, Mr.Qt, xp[b], up[b], Mr.lower,
+                                               Mr.upper, cost_kind=co.COST_PATHQR), x0, us0, n_it)
+    Mp = um.UserModel(um.load("planar_rotor_user"), T, Mr.user_params, Mr.Q, Mr.R, Mr.Qt, None, None, Mr.lower, Mr.upper,
+                      x_path=xp, u_path=up)
+    compare(um.solve(Mp, hip.Opts(max_iter=n_it), dev(x0), dev(us0)), refp, "rotor, paths")
