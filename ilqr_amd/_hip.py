@@ -522,52 +522,73 @@ def detmath(a, b):
 
 # ---- large-state path (n = 32, m = 8, one problem per wavefront) -----------------------------
 
+def pad_last(t, size, dims=1):
+    """``t`` with its last ``dims`` dimensions zero-padded to ``size`` (an int, or one int per dimension)."""
+    import torch
+    sizes = (size,) * dims if isinstance(size, int) else tuple(size)
+    if tuple(t.shape[-dims:]) == sizes:
+        return t.contiguous()
+    out = torch.zeros(tuple(t.shape[:-dims]) + sizes, dtype=t.dtype, device=t.device)
+    out[(Ellipsis,) + tuple(slice(0, s) for s in t.shape[-dims:])] = t
+    return out
+
+
 class LargeModel:
     """Synthetic model x+ = x + dt (A x + B u + c phi(W x)) with a QRCost and box limits; every
     array is uploaded once and kept alive by this object."""
 
     def __init__(self, T, A, B, W, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
                  dt=0.05, sig_c=2.0, device=None, x_path=None, u_path=None):
-        """x_path [T+1, 32], u_path [T, 8]: the goals of a PathQRCost instead of x_goal / u_goal.
-        One goal or path per problem: x_goal [B, 32], u_goal [B, 8] or x_path [B, T+1, 32], u_path [B, T, 8]."""
+        """A [n, n], B [n, m], W [n, n] with n <= 32 states and m <= 8 controls (the kernels work on 32 x 8; smaller
+        models are padded with zeros here, which leaves every result bit the same, see ilqr_large_model).
+        x_path [T+1, n], u_path [T, m]: the goals of a PathQRCost instead of x_goal / u_goal.
+        One goal or path per problem: x_goal [B, n], u_goal [B, m] or x_path [B, T+1, n], u_path [B, T, m]."""
         import torch
+        n_real, m_real = int(np.shape(A)[0]), int(np.shape(B)[1])
+        if not (1 <= n_real <= 32 and 1 <= m_real <= 8):
+            raise ValueError("the large-state path holds up to 32 states and 8 controls, not %d and %d" % (n_real, m_real))
         n, m = 32, 8
-        self.n, self.m, self.T = n, m, int(T)
+        self.n, self.m, self.T = n_real, m_real, int(T)
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
 
-        def up(a, shape):
-            return torch.tensor(_host(a, shape), device=dev)
+        nr, mr, T1 = n_real, m_real, int(T) + 1
+
+        def up(a, real, full):
+            """the array (of shape ``real``), zero-padded to ``full``, on the device"""
+            out = np.zeros(full)
+            out[tuple(slice(0, r) for r in real)] = _host(a, real)
+            return torch.tensor(out, device=dev)
         self.batch_goals = None
         per_problem_goal = x_path is None and x_goal is not None and _ndim(x_goal) == 2
         self.t = dict(
-            A=up(A, (n, n)), B=up(B, (n, m)), W=up(W, (n, n)), Q=up(Q, (n, n)), R=up(R, (m, m)),
-            Q_terminal=up(Q if Q_terminal is None else Q_terminal, (n, n)),
-            x_goal=up(np.zeros(n) if (x_goal is None or per_problem_goal) else x_goal, (n,)),
-            u_goal=up(np.zeros(m) if (u_goal is None or per_problem_goal) else u_goal, (m,)),
-            lower=up(lower, (m,)), upper=up(upper, (m,)))
+            A=up(A, (nr, nr), (n, n)), B=up(B, (nr, mr), (n, m)), W=up(W, (nr, nr), (n, n)), Q=up(Q, (nr, nr), (n, n)),
+            R=up(R, (mr, mr), (m, m)), Q_terminal=up(Q if Q_terminal is None else Q_terminal, (nr, nr), (n, n)),
+            x_goal=up(np.zeros(nr) if (x_goal is None or per_problem_goal) else x_goal, (nr,), (n,)),
+            u_goal=up(np.zeros(mr) if (u_goal is None or per_problem_goal) else u_goal, (mr,), (m,)),
+            lower=up(lower, (mr,), (m,)), upper=up(upper, (mr,), (m,)))
         c = LargeModelC()
-        c.n, c.m, c.T, c.dt, c.sig_c = n, m, int(T), dt, sig_c
+        c.n, c.m, c.T, c.dt, c.sig_c = n_real, m_real, int(T), dt, sig_c
         c.cost_kind = COST_QR
         if x_path is not None or u_path is not None:
             if x_path is None or u_path is None:
                 raise ValueError("PathQRCost needs both x_path and u_path")
             if _ndim(x_path) == 3:  # one path per problem
-                self.t["x_goal"], self.t["u_goal"] = _dev64(x_path, dev), _dev64(u_path, dev)
+                self.t["x_goal"], self.t["u_goal"] = pad_last(_dev64(x_path, dev), n), pad_last(_dev64(u_path, dev), m)
                 Bg = self.t["x_goal"].shape[0]
                 if tuple(self.t["x_goal"].shape) != (Bg, int(T) + 1, n) or tuple(self.t["u_goal"].shape) != (Bg, int(T), m):
-                    raise ValueError("per-problem paths must be x_path [B, T+1, 32] and u_path [B, T, 8]")
+                    raise ValueError("per-problem paths must be x_path [B, T+1, n] and u_path [B, T, m]")
                 self.batch_goals = int(Bg)
                 c.goal_stride_x, c.goal_stride_u = (int(T) + 1) * n, int(T) * m
             else:
-                self.t["x_goal"] = up(x_path, (int(T) + 1, n))
-                self.t["u_goal"] = up(u_path, (int(T), m))
+                self.t["x_goal"] = up(x_path, (T1, nr), (T1, n))
+                self.t["u_goal"] = up(u_path, (T1 - 1, mr), (T1 - 1, m))
             c.cost_kind = COST_PATH_QR
         elif per_problem_goal:
-            self.t["x_goal"] = _dev64(x_goal, dev)
+            self.t["x_goal"] = pad_last(_dev64(x_goal, dev), n)
             Bg = self.t["x_goal"].shape[0]
-            self.t["u_goal"] = _dev64(np.zeros((Bg, m)) if u_goal is None else u_goal, dev)
+            self.t["u_goal"] = pad_last(_dev64(np.zeros((Bg, m)) if u_goal is None else u_goal, dev), m)
             if tuple(self.t["x_goal"].shape) != (Bg, n) or tuple(self.t["u_goal"].shape) != (Bg, m):
-                raise ValueError("per-problem goals must be x_goal [B, 32] and u_goal [B, 8]")
+                raise ValueError("per-problem goals must be x_goal [B, n] and u_goal [B, m]")
             self.batch_goals = int(Bg)
             c.goal_stride_x, c.goal_stride_u = n, m
         for name, t in self.t.items():
@@ -598,14 +619,18 @@ def _check_goal_batch(M, B):
                          "model of a sub-batch)" % (M.batch_goals, B))
 
 
+LARGE_N, LARGE_M = 32, 8  # the sizes the large-state kernels work on (smaller models run zero-padded)
+
+
 def large_rollout_cost(M, x0, us):
     import torch
     B = x0.shape[0]
-    xs = torch.empty((B, M.T + 1, M.n), dtype=torch.float64, device=x0.device)
+    x0, us = pad_last(x0, LARGE_N), pad_last(us, LARGE_M)
+    xs = torch.empty((B, M.T + 1, LARGE_N), dtype=torch.float64, device=x0.device)
     J = torch.empty(B, dtype=torch.float64, device=x0.device)
     check(lib().ilqr_large_rollout_cost(C.byref(M.c), C.c_int64(B), _ptr(_req(x0, torch.float64)),
                                         _ptr(_req(us, torch.float64)), _ptr(xs), _ptr(J), _stream()))
-    return xs, J
+    return (xs if M.n == LARGE_N else xs[..., :M.n].contiguous()), J
 
 
 def large_deriv(M, xs, us, out=None):
@@ -629,15 +654,19 @@ def large_deriv(M, xs, us, out=None):
 def large_backward(M, O, xs, us, mu, want_masks=True):
     import torch
     B, dev = xs.shape[0], xs.device
-    k = torch.empty((B, M.T, M.m), dtype=torch.float64, device=dev)
-    K = torch.empty((B, M.T, M.m, M.n), dtype=torch.float64, device=dev)
+    xs, us = pad_last(xs, LARGE_N), pad_last(us, LARGE_M)
+    k = torch.empty((B, M.T, LARGE_M), dtype=torch.float64, device=dev)
+    K = torch.empty((B, M.T, LARGE_M, LARGE_N), dtype=torch.float64, device=dev)
     dJ = torch.empty((2, B), dtype=torch.float64, device=dev)
     info = torch.empty((5, B), dtype=torch.int32, device=dev)
     qres = torch.empty((B, M.T), dtype=torch.int32, device=dev) if want_masks else None
-    free = torch.empty((B, M.T, M.m), dtype=torch.int32, device=dev) if want_masks else None
+    free = torch.empty((B, M.T, LARGE_M), dtype=torch.int32, device=dev) if want_masks else None
     check(lib().ilqr_large_backward(C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
                                     _ptr(_req(us, torch.float64)), _ptr(_req(mu, torch.float64)), _ptr(k), _ptr(K),
                                     _ptr(dJ), _ptr(info), _ptr(qres), _ptr(free), _stream()))
+    if (M.n, M.m) != (LARGE_N, LARGE_M):
+        k, K = k[..., :M.m].contiguous(), K[..., :M.m, :M.n].contiguous()
+        free = None if free is None else free[..., :M.m].contiguous()
     return dict(k=k, K=K, dJ=dJ, info=info, qp_result=qres, free=free)
 
 
@@ -659,8 +688,14 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
     import torch
     B, dev = x0.shape[0], x0.device
     _check_goal_batch(M, B)
-    T, n, m = M.T, M.n, M.m
+    T, n, m = M.T, LARGE_N, LARGE_M
+    padded = (M.n, M.m) != (n, m)
     delta = torch.full((B,), 2.0, dtype=torch.float64, device=dev) if delta is None else delta
+    k_in, K_in = k, K
+    if padded:  # the kernels work on 32 x 8: zero-padded copies in, the leading entries out
+        x0, us_init = pad_last(x0, n), pad_last(us_init, m)
+        k = None if k is None else pad_last(k, m)
+        K = None if K is None else pad_last(K, (m, n), dims=2)
     k = torch.zeros((B, T, m), dtype=torch.float64, device=dev) if k is None else k
     K = torch.zeros((B, T, m, n), dtype=torch.float64, device=dev) if K is None else K
     res = dict(xs=torch.empty((B, T + 1, n), dtype=torch.float64, device=dev),
@@ -687,5 +722,12 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
         _ptr(_req(delta, torch.float64)), _ptr(_req(k, torch.float64)), _ptr(_req(K, torch.float64)),
         _ptr(res["xs"]), _ptr(res["us"]), _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),
         C.byref(tr_c) if tr_c is not None else None, _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
+    if padded:
+        res["xs"], res["us"] = res["xs"][..., :M.n].contiguous(), res["us"][..., :M.m].contiguous()
+        k, K = k[..., :M.m].contiguous(), K[..., :M.m, :M.n].contiguous()
+        if k_in is not None:  # in/out arguments: the caller's tensors receive the gains
+            k_in.copy_(k)
+            K_in.copy_(K)
+            k, K = k_in, K_in
     res.update(delta=delta, k=k, K=K, trace=tr, workspace=workspace)
     return res

@@ -251,61 +251,94 @@ __global__ __launch_bounds__(WAVE) void k_rollout_cost(CartpoleP mp, QRCostP Cp,
 
 // One thread per (problem, step): f_x, f_u, l_x, l_u, l_xx, l_uu, l_ux as dense
 // batch-minor streams (what _compute_Q_terms asks the model for, ilqr_core.py:189-198).
+// Two neighbouring problems per lane, so that every store instruction of a wavefront writes 64 x 16 bytes =
+// 1 KB of consecutive memory (the rows of the batch-minor streams are `ld` doubles long and ld is a multiple of
+// 64, so an even problem index is 16-byte aligned in every row).
+struct DerivOne { // the derivative tensors of one (problem, step), row-major
+    double fx[NX * NX], fu[NX], lx[NX], lu, luu;
+};
 template <class Cost>
-__global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP Cp, int T, int64_t B, int64_t ld,
-                                               const double* __restrict__ xs,
-                                               const double* __restrict__ us, ilqr_deriv_bm_t o)
+__device__ __forceinline__ void deriv_one(const CartpoleC& P, const Cost& C, const double (&x)[NX], double u, int t,
+                                          DerivOne& d)
 {
-    int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int t = blockIdx.y;
-    if (b >= B)
-        return;
-    CartpoleC P = cartpole_consts(mp);
-    Cost C(Cp);
-    double x[NX];
-    load5(xs, ld, (int64_t)t * NX, b, x);
-    if (t == T) { // terminal l_x, l_xx (ilqr_core.py:120-121)
-        double lx[NX];
-        C.at_terminal(T);
-        C.lx_terminal(x, lx);
-        store5(o.lxT, ld, 0, b, lx);
-        for (int i = 0; i < NX * NX; ++i)
-            o.lxxT[(int64_t)i * ld + b] = Cp.QQt[i];
-        return;
-    }
-    double u = us[(int64_t)t * ld + b];
     double th = det_atan2(x[2], x[3]);
     double sn, cn;
     det_sincos(th + x[4] * P.dt, sn, cn);
     CartpoleJac J;
     cartpole_jac(P, x, u, sn, cn, J);
-    double fx[NX * NX];
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i)
-        fx[i] = 0.0;
-    fx[0] = 1.0;
-    fx[1] = P.dt;
-    fx[1 * NX + 1] = 1.0;
+        d.fx[i] = 0.0;
+    d.fx[0] = 1.0;
+    d.fx[1] = P.dt;
+    d.fx[1 * NX + 1] = 1.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            fx[(r + 1) * NX + 2 + c] = J.a[r][c];
-    int64_t base = (int64_t)t * NX * NX;
+            d.fx[(r + 1) * NX + 2 + c] = J.a[r][c];
+    d.fu[0] = 0.0;
+    d.fu[1] = J.b1;
+    d.fu[2] = 0.0;
+    d.fu[3] = 0.0;
+    d.fu[4] = J.b4;
+    C.at(t);
+    C.lx(x, d.lx);
+    d.lu = C.lu(u);
+    d.luu = C.luu();
+}
+__device__ __forceinline__ void store_pair(double* row, int64_t b, bool two, double v0, double v1)
+{
+    if (two)
+        *reinterpret_cast<double2*>(row + b) = make_double2(v0, v1);
+    else
+        row[b] = v0;
+}
+template <class Cost>
+__global__ __launch_bounds__(256) void k_deriv(CartpoleP mp, QRCostP Cp, int T, int64_t B, int64_t ld,
+                                               const double* __restrict__ xs,
+                                               const double* __restrict__ us, ilqr_deriv_bm_t o)
+{
+    const int64_t b = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x); // problems b and b + 1
+    const int t = blockIdx.y;
+    if (b >= B)
+        return;
+    const bool two = b + 1 < B;
+    const int64_t b1 = two ? b + 1 : b;
+    CartpoleC P = cartpole_consts(mp);
+    Cost C(Cp);
+    double x0[NX], x1[NX];
+    load5(xs, ld, (int64_t)t * NX, b, x0);
+    load5(xs, ld, (int64_t)t * NX, b1, x1);
+    if (t == T) { // terminal l_x, l_xx (ilqr_core.py:120-121)
+        double l0[NX], l1[NX];
+        C.at_terminal(T);
+        C.lx_terminal(x0, l0);
+        C.lx_terminal(x1, l1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            store_pair(o.lxT + (int64_t)i * ld, b, two, l0[i], l1[i]);
+        for (int i = 0; i < NX * NX; ++i)
+            store_pair(o.lxxT + (int64_t)i * ld, b, two, Cp.QQt[i], Cp.QQt[i]);
+        return;
+    }
+    DerivOne d0, d1;
+    deriv_one(P, C, x0, us[(int64_t)t * ld + b], t, d0);
+    deriv_one(P, C, x1, us[(int64_t)t * ld + b1], t, d1);
+    const int64_t base = (int64_t)t * NX * NX;
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) {
-        o.fx[(base + i) * ld + b] = fx[i];
-        o.lxx[(base + i) * ld + b] = Cp.QQ[i];
+        store_pair(o.fx + (base + i) * ld, b, two, d0.fx[i], d1.fx[i]);
+        store_pair(o.lxx + (base + i) * ld, b, two, Cp.QQ[i], Cp.QQ[i]);
     }
-    double fu[NX] = {0.0, J.b1, 0.0, 0.0, J.b4};
-    double lx[NX], zero[NX] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    C.at(t);
-    C.lx(x, lx);
-    store5(o.fu, ld, (int64_t)t * NX, b, fu);
-    store5(o.lx, ld, (int64_t)t * NX, b, lx);
-    store5(o.lux, ld, (int64_t)t * NX, b, zero);
-    o.lu[(int64_t)t * ld + b] = C.lu(u);
-    o.luu[(int64_t)t * ld + b] = C.luu();
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        store_pair(o.fu + ((int64_t)t * NX + i) * ld, b, two, d0.fu[i], d1.fu[i]);
+        store_pair(o.lx + ((int64_t)t * NX + i) * ld, b, two, d0.lx[i], d1.lx[i]);
+        store_pair(o.lux + ((int64_t)t * NX + i) * ld, b, two, 0.0, 0.0);
+    }
+    store_pair(o.lu + (int64_t)t * ld, b, two, d0.lu, d1.lu);
+    store_pair(o.luu + (int64_t)t * ld, b, two, d0.luu, d1.luu);
 }
 
 // ------------------------------------------------------------ backward pass
@@ -2189,10 +2222,10 @@ int ilqr_deriv_bm(const ilqr_model* model, int64_t B, int64_t ld, const double* 
     BoundsP bd;
     fill_model(model, mp, C, bd);
     if (C.x_path != nullptr)
-        hipLaunchKernelGGL(k_deriv<PathQR>, dim3((unsigned)((B + 255) / 256), (unsigned)(model->T + 1)), dim3(256),
+        hipLaunchKernelGGL(k_deriv<PathQR>, dim3((unsigned)((B + 511) / 512), (unsigned)(model->T + 1)), dim3(256),
                            0, as_stream(stream), mp, C, model->T, B, ld, xs, us, *out);
     else
-        hipLaunchKernelGGL(k_deriv<DenseQR>, dim3((unsigned)((B + 255) / 256), (unsigned)(model->T + 1)), dim3(256),
+        hipLaunchKernelGGL(k_deriv<DenseQR>, dim3((unsigned)((B + 511) / 512), (unsigned)(model->T + 1)), dim3(256),
                            0, as_stream(stream), mp, C, model->T, B, ld, xs, us, *out);
     return hip_status(hipGetLastError());
 }

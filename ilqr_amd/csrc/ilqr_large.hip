@@ -146,6 +146,10 @@ struct LQPOpts {
     int max_iter;
     int n_exhaust; // number of step reductions after which step < min_step (host-simulated)
     double min_grad, min_rel, step_dec, min_step, armijo;
+    // A model with fewer than 8 controls runs zero-padded (see large_check): the padded controls have zero rows in
+    // every matrix and the limits [0, 0]; for boxQP they are permanently clamped variables that no chain sees.
+    unsigned real_mask; // bit i set: control i exists
+    int m_real;
 };
 
 
@@ -335,8 +339,9 @@ __device__ __forceinline__ void lr_solve(const double (&Lf)[LM][LM], const doubl
 }
 
 // cho_solve with the all-ones "factor" H_ff = np.ones((n, n)) of ilqr_boxQP.py:36 (used until the
-// first factorisation, which can only be while nothing is clamped)
-__device__ __forceinline__ void lr_solve_ones(double (&b)[LM])
+// first factorisation, which can only be while nothing is clamped); `real`: the controls that exist (a model
+// with fewer than 8 runs zero-padded, and the reference's matrix of ones has the size of the real problem)
+__device__ __forceinline__ void lr_solve_ones(double (&b)[LM], unsigned real)
 {
 #pragma unroll
     for (int i = 0; i < LM; ++i) {
@@ -344,7 +349,7 @@ __device__ __forceinline__ void lr_solve_ones(double (&b)[LM])
 #pragma unroll
         for (int j = 0; j < i; ++j)
             s = fma(-1.0, b[j], s);
-        b[i] = s * 1.0;
+        b[i] = (real & (1u << i)) ? s * 1.0 : 0.0;
     }
 #pragma unroll
     for (int i = LM - 1; i >= 0; --i) {
@@ -352,7 +357,7 @@ __device__ __forceinline__ void lr_solve_ones(double (&b)[LM])
 #pragma unroll
         for (int j = i + 1; j < LM; ++j)
             s = fma(-1.0, b[j], s);
-        b[i] = s * 1.0;
+        b[i] = (real & (1u << i)) ? s * 1.0 : 0.0;
     }
 }
 
@@ -450,7 +455,8 @@ __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR
     const int ln = threadIdx.x & 63;
     const V8 gV = v8_load(Q.g, L.g), loV = v8_load(Q.lo, L.g), hiV = v8_load(Q.hi, L.g);
     V8 x{lclamp(loV.a, hiV.a, Q.x.a), lclamp(loV.b, hiV.b, Q.x.b)};
-    unsigned clm = 0; // clamped set of the last classification
+    const unsigned pad = ~O.real_mask & 0xffu; // controls that only pad the problem to 8
+    unsigned clm = pad; // clamped set of the last classification (none of the real controls: ilqr_boxQP.py:27-28)
     Q.frm = 0;
     Q.factored = false;
     double value = h8_value(H, gV, x), oldvalue = 0.0;
@@ -471,7 +477,7 @@ __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR
         const V8 grad{gV.a + hx.a, gV.b + hx.b};
         const bool ca = ((x.a == loV.a) && (grad.a > 0.0)) || ((x.a == hiV.a) && (grad.a < 0.0));
         const bool cb = ((x.b == loV.b) && (grad.b > 0.0)) || ((x.b == hiV.b) && (grad.b < 0.0));
-        const unsigned ncl = v8_mask(ca, cb);
+        const unsigned ncl = v8_mask(ca, cb) | pad;
         const bool changed = ncl != clm;
         clm = ncl;
         Q.frm = ~clm & 0xffu;
@@ -524,7 +530,7 @@ __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR
             if (Q.factored)
                 lr_solve(Q.Lf, Q.rd, Q.frm, rhs);
             else
-                lr_solve_ones(rhs);
+                lr_solve_ones(rhs, O.real_mask);
             const V8 sol = v8_of(rhs, L.g);
             search.a = ca ? 0.0 : sol.a * -1 - x.a;
             search.b = cb ? 0.0 : sol.b * -1 - x.b;
@@ -893,7 +899,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         qr.lo = S.lo;
         qr.hi = S.hi;
         {
-            if (lr_chol(Hq, 0xffu, qr.Lf, qr.rd)) {
+            if (lr_chol(Hq, QO.real_mask, qr.Lf, qr.rd)) {
                 out.stopped_at = i;
                 break;
             }
@@ -902,9 +908,9 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 #pragma unroll
             for (int a = 0; a < LM; ++a)
                 ws[a] = S.g[a];
-            lr_solve(qr.Lf, qr.rd, 0xffu, ws);
+            lr_solve(qr.Lf, qr.rd, QO.real_mask, ws);
             qr.x = v8_of(ws, L.g);
-            qr.fmask = 0xffu;
+            qr.fmask = QO.real_mask;
         }
         long long t_b1 = prof ? clock64() : 0;
         lr_boxqp(QO, Hq, M.steps, qr);
@@ -915,7 +921,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         }
         out.qp_iter += qr.n_iter;
         out.qp_backtrack += qr.n_bt;
-        out.n_clamped += qr.nf < LM ? 1 : 0;
+        out.n_clamped += qr.nf < QO.m_real ? 1 : 0;
         if (qp_result && lane == 0)
             qp_result[i] = qr.result;
         if (free_mask && lane == 0) {
@@ -941,7 +947,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
                 if (qr.factored)
                     lr_solve(qr.Lf, qr.rd, qr.frm, col);
                 else
-                    lr_solve_ones(col);
+                    lr_solve_ones(col, QO.real_mask);
             }
 #pragma unroll
             for (int a = 0; a < LM; ++a)
@@ -1518,13 +1524,18 @@ __global__ __launch_bounds__(256) void k_large_deriv(LargeP P, int64_t B, const 
     const int ns = (T - t0) < DS ? (T - t0) : DS; // steps t < T of this chunk
     for (int s = 0; s < ns; ++s) {
         const int64_t bt = b * T + t0 + s;
-        for (int e = tid; e < LN * LN; e += 256) {
+        // 16 bytes per lane and store: elements e, e + 1 of a row (same i, columns j and j + 1)
+        for (int e = 2 * tid; e < LN * LN; e += 512) {
             int i = e >> 5, j = e & 31;
-            o.fx[bt * LN * LN + e] = (i == j ? 1.0 : 0.0) + P.dt * (P.A[e] + s_g[s][i] * s_W[i][j]);
-            o.lxx[bt * LN * LN + e] = s_QQ[i][j];
+            double v0 = (i == j ? 1.0 : 0.0) + P.dt * (P.A[e] + s_g[s][i] * s_W[i][j]);
+            double v1 = (i == j + 1 ? 1.0 : 0.0) + P.dt * (P.A[e + 1] + s_g[s][i] * s_W[i][j + 1]);
+            *reinterpret_cast<double2*>(o.fx + bt * LN * LN + e) = make_double2(v0, v1);
+            *reinterpret_cast<double2*>(o.lxx + bt * LN * LN + e) = make_double2(s_QQ[i][j], s_QQ[i][j + 1]);
         }
-        o.fu[bt * LN * LM + tid] = P.dt * P.B[tid];
-        o.lux[bt * LM * LN + tid] = 0.0;
+        if (tid < LN * LM / 2) {
+            *reinterpret_cast<double2*>(o.fu + bt * LN * LM + 2 * tid) = make_double2(P.dt * P.B[2 * tid], P.dt * P.B[2 * tid + 1]);
+            *reinterpret_cast<double2*>(o.lux + bt * LM * LN + 2 * tid) = make_double2(0.0, 0.0);
+        }
         if (tid < LM * LM)
             o.luu[bt * LM * LM + tid] = s_RR[tid / LM][tid % LM];
     }
@@ -1536,7 +1547,7 @@ int large_check(const ilqr_large_model* m)
 {
     if (!m)
         return ILQR_ERR_ARG;
-    if (m->n != LN || m->m != LM)
+    if (m->n < 1 || m->n > LN || m->m < 1 || m->m > LM)
         return ILQR_ERR_UNSUPPORTED;
     if (m->T < 1 || !m->A || !m->B || !m->W || !m->Q || !m->R || !m->Q_terminal || !m->x_goal || !m->u_goal ||
         !m->lower || !m->upper)
@@ -1575,8 +1586,10 @@ LargeP large_fill(const ilqr_large_model* m)
     return P;
 }
 
-int large_qp(const ilqr_opts* o, LQPOpts& q)
+int large_qp(const ilqr_opts* o, LQPOpts& q, const ilqr_large_model* m)
 {
+    q.m_real = m->m;
+    q.real_mask = (1u << m->m) - 1u;
     if (!o || o->qp_max_iter < 0 || !(o->qp_step_dec > 0.0) || !(o->qp_step_dec < 1.0) || !(o->qp_min_step > 0.0))
         return ILQR_ERR_ARG;
     q.max_iter = o->qp_max_iter;
@@ -1648,7 +1661,7 @@ int ilqr_large_backward(const ilqr_large_model* model, const ilqr_opts* opts, in
     if (rc != ILQR_OK)
         return rc;
     LQPOpts q;
-    rc = large_qp(opts, q);
+    rc = large_qp(opts, q, model);
     if (rc != ILQR_OK)
         return rc;
     if (B < 1 || !xs || !us || !mu || !k || !K || !dJ || !info)
@@ -1738,7 +1751,7 @@ int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opt
     O.dJ_carry = opts->dJ_carry;
     for (int i = 0; i < 32; ++i)
         O.alphas[i] = i < opts->n_alpha ? opts->alphas[i] : 0.0;
-    rc = large_qp(opts, O.qp);
+    rc = large_qp(opts, O.qp, model);
     if (rc != ILQR_OK)
         return rc;
     size_t T = (size_t)model->T;

@@ -20,20 +20,21 @@ class SigmoidLinearDynamics(Dynamics):
         self.A = np.array(A, dtype=np.float64)
         self.B = np.array(B, dtype=np.float64)
         self.W = np.array(W, dtype=np.float64)
-        assert self.A.shape == (32, 32) and self.W.shape == (32, 32) and self.B.shape == (32, 8), \
-            "the device model is built for 32 states and 8 controls"
+        n, m = self.A.shape[0], self.B.shape[1]
+        assert self.A.shape == (n, n) and self.W.shape == (n, n) and self.B.shape == (n, m), "A, W [n, n], B [n, m]"
+        assert 1 <= n <= 32 and 1 <= m <= 8, "the device model holds up to 32 states and 8 controls"
         self.tau = float(dt)
         self.sig_c = float(sig_c)
-        self.upper_bound = np.full(8, float(max_control))
-        self.lower_bound = np.full(8, -float(max_control))
+        self.upper_bound = np.full(m, float(max_control))
+        self.lower_bound = np.full(m, -float(max_control))
 
     @property
     def state_dimension(self):
-        return 32
+        return self.A.shape[0]
 
     @property
     def control_dimension(self):
-        return 8
+        return self.B.shape[1]
 
     @property
     def has_hessians(self):
@@ -47,7 +48,7 @@ class SigmoidLinearDynamics(Dynamics):
         z = self.W.dot(x)
         s = 1.0 + z * z
         g = self.sig_c / (s * np.sqrt(s))
-        return np.eye(32) + self.tau * (self.A + g[:, None] * self.W)
+        return np.eye(self.A.shape[0]) + self.tau * (self.A + g[:, None] * self.W)
 
     def f_u(self, x, u, i):
         return self.tau * self.B

@@ -272,7 +272,13 @@ int ilqr_detmath(int64_t n, const double* a, const double* b, double* sin_a, dou
  * reference's own layout ([B,T+1,n], [B,T,m], [B,T,m,n]); no batch-minor conversion.
  * Every pointer of this struct is a DEVICE pointer (the matrices are read by the kernels). */
 typedef struct ilqr_large_model {
-    int32_t n, m, T;  /* n must be 32, m must be 8 */
+    int32_t n, m, T;  /* 1 <= n <= 32 states, 1 <= m <= 8 controls.  The kernels work on 32 x 8: every array of
+                         this struct and of the entry points keeps the full-size layout ([32*32], [32*8], [8*8],
+                         [32], [8]; trajectories [B,T+1,32], [B,T,8], gains [B,T,8,32]) with the entries beyond n
+                         and m ZERO (limits of a padded control: lower = upper = 0).  Padding adds exact zeros to
+                         the end of every sum of the reference's arithmetic, so the first n / m entries of every
+                         result equal the n x m computation bit for bit, and boxQP treats the padded controls as
+                         variables that do not exist (result codes, free sets and counters are those of m). */
     int32_t cost_kind; /* ILQR_COST_QR, or ILQR_COST_PATH_QR: x_goal [T+1][n], u_goal [T][m] hold the goals
                           of every time step (PathQRCost, ilqr/ilqr_cost.py:635-770) */
     double dt, sig_c; /* step and the gain c of the non-linearity */

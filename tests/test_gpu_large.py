@@ -337,3 +337,41 @@ def test_large_backward_on_converged_trajectories(hip, qp):
     assert np.array_equal(info[0], ref["stopped_at"]) and np.array_equal(info[3], ref["n_clamped"])
     exhausted = (ref["qp_result"] == 2).mean()
     assert exhausted > 0.05, exhausted  # the path is really taken
+
+
+@pytest.mark.parametrize("n,m", [(16, 4), (24, 8), (32, 3), (9, 1), (20, 5)])
+def test_large_path_with_fewer_states_and_controls(hip, n, m):
+    """Models between the per-model libraries (n <= 8) and the full 32 x 8: the large-state kernels run them
+    zero-padded, and every sum of the reference's arithmetic only gains exact zeros at its end, so the n x m
+    oracle solve must come back bit for bit -- trajectories, gains, regularisation state, and the boxQP's result
+    codes, free sets and counters (the padded controls must not exist for it: the all-clamped exit, the
+    single-free-variable norm and the factorisation count depend on m)."""
+    T, B, n_it = 40, 30, 20
+    Mo = co.synthetic_model(n=n, m=m, T=T, seed=40 + n + m, u_max=0.6)
+    M = hip.LargeModel(T, Mo.A, Mo.B, Mo.W, Mo.Q, Mo.R, Mo.Qt, Mo.x_goal, Mo.u_goal, Mo.lower, Mo.upper, dt=Mo.dt,
+                       sig_c=Mo.sig_c)
+    assert (M.n, M.m) == (n, m)
+    x0, us0 = co.synthetic_batch(B, n=n, m=m, T=T, seed_x=50 + n, seed_u=60 + m)
+    us0 *= 2.0
+    ref = co.solve(Mo, co.Opts(max_iter=n_it), x0, us0, nthreads=8)
+    out = hip.large_solve(M, hip.Opts(max_iter=n_it), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    _compare_solve(out, ref, B)
+    assert (ref["trace"]["n_clamped"] > 0).any()
+    # stage level: one backward sweep with result codes and free sets
+    xs, _ = co.rollout_cost(Mo, x0, us0)
+    bw_ref = co.backward(Mo, co.Opts(), xs, us0, np.ones(B))
+    bw = hip.large_backward(M, hip.Opts(), dev(xs), dev(us0), dev(np.ones(B)))
+    assert eq(bw["k"].cpu().numpy(), bw_ref["k"]) and eq(bw["K"].cpu().numpy(), bw_ref["K"])
+    assert np.array_equal(bw["qp_result"].cpu().numpy(), bw_ref["qp_result"])
+    assert np.array_equal(bw["free"].cpu().numpy(), bw_ref["free"])
+    info = bw["info"].cpu().numpy()
+    assert np.array_equal(info[1], bw_ref["qp_iter"]) and np.array_equal(info[2], bw_ref["qp_backtrack"])
+    assert np.array_equal(info[3], bw_ref["n_clamped"])
+    # through the solver API
+    from ilqr_amd import QRCost, iLQR
+    from ilqr_amd.synthetic import SigmoidLinearDynamics
+    dyn = SigmoidLinearDynamics(Mo.A, Mo.B, Mo.W, dt=Mo.dt, sig_c=Mo.sig_c, max_control=0.6)
+    s = iLQR(dyn, QRCost(Mo.Q, Mo.R, Q_terminal=Mo.Qt), T)
+    xs_a, us_a = s.update_u(x0, us0, n_iterations=n_it)
+    assert xs_a.shape == (B, T + 1, n) and eq(xs_a, ref["xs"]) and eq(us_a, ref["us"]) and eq(s.K_, ref["K"])
