@@ -446,8 +446,11 @@ __device__ __forceinline__ bool armijo_exhausts(const H8& H, const V8& g, const 
 // On entry Q.x holds the warm start and Q.Lf / Q.rd / Q.fmask the factor of the full H (the caller
 // needed it for the warm start): a factorisation for a free set that Lf already belongs to is not
 // repeated (same inputs, same bits); the reference's counter still counts it.
+// FULL: all 8 controls exist (the masks for padded controls are then compile-time constants and cost nothing).
+template <bool FULL>
 __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR& Q)
 {
+    const unsigned real_mask = FULL ? 0xffu : O.real_mask;
 #ifdef ILQR_LARGE_QP_PROF
     unsigned long long lqp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -455,7 +458,7 @@ __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR
     const int ln = threadIdx.x & 63;
     const V8 gV = v8_load(Q.g, L.g), loV = v8_load(Q.lo, L.g), hiV = v8_load(Q.hi, L.g);
     V8 x{lclamp(loV.a, hiV.a, Q.x.a), lclamp(loV.b, hiV.b, Q.x.b)};
-    const unsigned pad = ~O.real_mask & 0xffu; // controls that only pad the problem to 8
+    const unsigned pad = ~real_mask & 0xffu; // controls that only pad the problem to 8
     unsigned clm = pad; // clamped set of the last classification (none of the real controls: ilqr_boxQP.py:27-28)
     Q.frm = 0;
     Q.factored = false;
@@ -530,7 +533,7 @@ __device__ void lr_boxqp(const LQPOpts& O, const H8& H, const double* steps, QPR
             if (Q.factored)
                 lr_solve(Q.Lf, Q.rd, Q.frm, rhs);
             else
-                lr_solve_ones(rhs, O.real_mask);
+                lr_solve_ones(rhs, real_mask);
             const V8 sol = v8_of(rhs, L.g);
             search.a = ca ? 0.0 : sol.a * -1 - x.a;
             search.b = cb ? 0.0 : sol.b * -1 - x.b;
@@ -739,11 +742,14 @@ struct BwOut {
 
 // _backward_pass + _compute_Q_terms (ilqr_core.py:109-228) for one problem.
 // xs [T+1][32], us [T][8] -> k [T][8], K [T][8][32] (zeros where the sweep does not reach).
-template <bool PATH>
+template <bool PATH, bool FULL>
 __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMem& M, WaveMem& S, const double* xs,
                                const double* us, double mu, double* k, double* K, BwOut& out, int32_t* qp_result,
                                int32_t* free_mask)
 {
+    // (a model with fewer than 8 controls runs zero-padded: FULL = false, masks from the options)
+    const unsigned real_mask = FULL ? 0xffu : QO.real_mask;
+    const int m_real = FULL ? LM : QO.m_real;
     const LaneId L = lane_id();
     const int T = P.T;
     const int lane = threadIdx.x & 63;
@@ -899,7 +905,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         qr.lo = S.lo;
         qr.hi = S.hi;
         {
-            if (lr_chol(Hq, QO.real_mask, qr.Lf, qr.rd)) {
+            if (lr_chol(Hq, real_mask, qr.Lf, qr.rd)) {
                 out.stopped_at = i;
                 break;
             }
@@ -908,12 +914,12 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 #pragma unroll
             for (int a = 0; a < LM; ++a)
                 ws[a] = S.g[a];
-            lr_solve(qr.Lf, qr.rd, QO.real_mask, ws);
+            lr_solve(qr.Lf, qr.rd, real_mask, ws);
             qr.x = v8_of(ws, L.g);
-            qr.fmask = QO.real_mask;
+            qr.fmask = real_mask;
         }
         long long t_b1 = prof ? clock64() : 0;
-        lr_boxqp(QO, Hq, M.steps, qr);
+        lr_boxqp<FULL>(QO, Hq, M.steps, qr);
         long long t_b2 = prof ? clock64() : 0;
         if (qr.linalg) {
             out.rc = 2;
@@ -921,7 +927,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         }
         out.qp_iter += qr.n_iter;
         out.qp_backtrack += qr.n_bt;
-        out.n_clamped += qr.nf < QO.m_real ? 1 : 0;
+        out.n_clamped += qr.nf < m_real ? 1 : 0;
         if (qp_result && lane == 0)
             qp_result[i] = qr.result;
         if (free_mask && lane == 0) {
@@ -947,7 +953,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
                 if (qr.factored)
                     lr_solve(qr.Lf, qr.rd, qr.frm, col);
                 else
-                    lr_solve_ones(col, QO.real_mask);
+                    lr_solve_ones(col, real_mask);
             }
 #pragma unroll
             for (int a = 0; a < LM; ++a)
@@ -1094,21 +1100,41 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
     Xh[0][0] = load_v(x0, LN, 0, L);
     Xh[1][0] = load_v(x0, LN, 1, L);
     double J = 0.0; // meaningful on the diagonal lanes (row == column) of tile (0, 0)
+    // The operands of a step (old u, x, k, K) are loaded one step ahead: a step's first product waits for them,
+    // and nothing else of the step can start before it.
+    struct StepOps {
+        d4 uv, xo0, xo1, K0, K1, kv;
+    };
+    auto fetch = [&](int t) {
+        StepOps o;
+        o.uv = load_v(us + (size_t)t * LM, LM, 0, L);
+        if (!ROLL) {
+            o.xo0 = load_v(xs + (size_t)t * LN, LN, 0, L);
+            o.xo1 = load_v(xs + (size_t)t * LN, LN, 1, L);
+            o.K0 = load_nt(K + (size_t)t * LM * LN, LN, LM, LN, 0, 0, L);
+            o.K1 = load_nt(K + (size_t)t * LM * LN, LN, LM, LN, 1, 0, L);
+            o.kv = load_v(k + (size_t)t * LM, LM, 0, L);
+        }
+        return o;
+    };
+    StepOps nxt = fetch(0);
     for (int t = 0; t < T; ++t) {
+        const StepOps op = nxt;
+        if (t + 1 < T)
+            nxt = fetch(t + 1);
         d4 Uh[1][1];
-        d4 uv = load_v(us + (size_t)t * LM, LM, 0, L);
+        const d4 uv = op.uv;
         if (ROLL) {
             Uh[0][0] = uv;
         } else {
             // u_new = u + alpha k + K (x_new - x)   (:104, never clamped)
             d4 dX[2][1], KT[2][1], acc[1][1];
-            dX[0][0] = Xh[0][0] - load_v(xs + (size_t)t * LN, LN, 0, L);
-            dX[1][0] = Xh[1][0] - load_v(xs + (size_t)t * LN, LN, 1, L);
-            KT[0][0] = load_nt(K + (size_t)t * LM * LN, LN, LM, LN, 0, 0, L);
-            KT[1][0] = load_nt(K + (size_t)t * LM * LN, LN, LM, LN, 1, 0, L);
+            dX[0][0] = Xh[0][0] - op.xo0;
+            dX[1][0] = Xh[1][0] - op.xo1;
+            KT[0][0] = op.K0;
+            KT[1][0] = op.K1;
             mm_tn<2, 1, 1>(KT, dX, acc);
-            d4 kv = load_v(k + (size_t)t * LM, LM, 0, L);
-            Uh[0][0] = (uv + alpha_c * kv) + acc[0][0];
+            Uh[0][0] = (uv + alpha_c * op.kv) + acc[0][0];
         }
         if (store_col >= 0 && L.c == store_col) {
 #pragma unroll
@@ -1204,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_large_rollout_cost(LargeP P, int64_t B,
         J[b] = S.J[0];
 }
 
-template <bool PATH>
+template <bool PATH, bool FULL>
 __global__ __launch_bounds__(256) void k_large_backward(LargeP P, LQPOpts QO, int64_t B, const double* xs,
                                                         const double* us, const double* mu, double* k, double* K,
                                                         double* dJ, int32_t* info, int32_t* qp_result,
@@ -1217,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_large_backward(LargeP P, LQPOpts QO, in
         return;
     WaveMem& S = M.wv[threadIdx.x >> 6];
     BwOut o;
-    large_backward<PATH>(for_problem(P, b), QO, M, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
+    large_backward<PATH, FULL>(for_problem(P, b), QO, M, S, xs + b * (P.T + 1) * LN, us + b * P.T * LM, mu[b], k + b * P.T * LM,
                    K + b * P.T * LM * LN, o, qp_result ? qp_result + b * P.T : nullptr,
                    free_mask ? free_mask + b * P.T * LM : nullptr);
     if ((threadIdx.x & 63) == 0) {
@@ -1268,7 +1294,7 @@ struct LSolveBuf {
 };
 
 // iLQR.update_u (ilqr_core.py:241-399) for problem b, run by one wavefront.
-template <bool PATH>
+template <bool PATH, bool FULL>
 __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSolveOpts& O, BlockMem& M, WaveMem& S,
                                                 const int64_t b, const int64_t B, const double* x0,
                                                 const double* us_init, double* delta_io, double* k0, double* K0,
@@ -1306,7 +1332,7 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
         // backward pass with the LinAlgError retry loop (:287-299); when it gives up at mu_max
         // the line search below still runs on the previous gains and Delta_J terms, as in the reference
         for (;;) {
-            large_backward<PATH>(P, O.qp, M, S, xsb[cur], usb[cur], mu, kb[gcur ^ 1], Kb[gcur ^ 1], bw, nullptr, nullptr);
+            large_backward<PATH, FULL>(P, O.qp, M, S, xsb[cur], usb[cur], mu, kb[gcur ^ 1], Kb[gcur ^ 1], bw, nullptr, nullptr);
             wave_sync();
             if (bw.rc == 0) {
                 gcur ^= 1;
@@ -1429,7 +1455,7 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
 // when the counter has passed B.  Iteration counts differ widely between problems (mean 11, maximum 116 on
 // the synthetic workload), so a workgroup of four fixed problems would hold its CU until the slowest of the
 // four has ended.  Which wavefront solves which problem has no influence on the results.
-template <bool PATH>
+template <bool PATH, bool FULL>
 __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int64_t B, const double* x0,
                                                      const double* us_init, double* delta_io, double* k0, double* K0,
                                                      double* xs0, double* us0, LSolveBuf W, int* queue, double* J_out,
@@ -1446,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_large_solve(LargeP P, LSolveOpts O, int
         const int64_t b = __builtin_amdgcn_readfirstlane(next);
         if (b >= B)
             break;
-        large_solve_one<PATH>(P, O, M, S, b, B, x0, us_init, delta_io, k0, K0, xs0, us0, W, J_out, mu_out, iters_out,
+        large_solve_one<PATH, FULL>(P, O, M, S, b, B, x0, us_init, delta_io, k0, K0, xs0, us0, W, J_out, mu_out, iters_out,
                               status_out, tr);
     }
 }
@@ -1666,13 +1692,20 @@ int ilqr_large_backward(const ilqr_large_model* model, const ilqr_opts* opts, in
         return rc;
     if (B < 1 || !xs || !us || !mu || !k || !K || !dJ || !info)
         return ILQR_ERR_ARG;
-    if (model->cost_kind == ILQR_COST_PATH_QR) {
-        hipLaunchKernelGGL(k_large_backward<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), q, B, xs, us,
-                           mu, k, K, dJ, info, qp_result, free_mask);
-    } else {
-        hipLaunchKernelGGL(k_large_backward<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ls(stream), large_fill(model), q, B, xs, us,
-                           mu, k, K, dJ, info, qp_result, free_mask);
-    }
+    const bool path = model->cost_kind == ILQR_COST_PATH_QR, full = model->m == LM;
+    const dim3 grid((unsigned)((B + 3) / 4));
+#define ILQR_LAUNCH_LB(PATH_, FULL_)                                                                                   \
+    hipLaunchKernelGGL((k_large_backward<PATH_, FULL_>), grid, dim3(256), 0, ls(stream), large_fill(model), q, B, xs, us, \
+                       mu, k, K, dJ, info, qp_result, free_mask)
+    if (path && full)
+        ILQR_LAUNCH_LB(true, true);
+    else if (path)
+        ILQR_LAUNCH_LB(true, false);
+    else if (full)
+        ILQR_LAUNCH_LB(false, true);
+    else
+        ILQR_LAUNCH_LB(false, false);
+#undef ILQR_LAUNCH_LB
     return lrc(hipGetLastError());
 }
 
@@ -1783,13 +1816,19 @@ int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opt
         tr = *trace;
     else
         std::memset(&tr, 0, sizeof(tr));
-    if (model->cost_kind == ILQR_COST_PATH_QR) {
-        hipLaunchKernelGGL(k_large_solve<true>, dim3((unsigned)groups), dim3(256), 0, ls(stream), large_fill(model), O, B,
-                           x0, us_init, delta, k, K, xs, us, W, queue, J, mu, iters, status, tr);
-    } else {
-        hipLaunchKernelGGL(k_large_solve<false>, dim3((unsigned)groups), dim3(256), 0, ls(stream), large_fill(model), O, B,
-                           x0, us_init, delta, k, K, xs, us, W, queue, J, mu, iters, status, tr);
-    }
+    const bool path = model->cost_kind == ILQR_COST_PATH_QR, full = model->m == LM;
+#define ILQR_LAUNCH_LS(PATH_, FULL_)                                                                                   \
+    hipLaunchKernelGGL((k_large_solve<PATH_, FULL_>), dim3((unsigned)groups), dim3(256), 0, ls(stream), large_fill(model), \
+                       O, B, x0, us_init, delta, k, K, xs, us, W, queue, J, mu, iters, status, tr)
+    if (path && full)
+        ILQR_LAUNCH_LS(true, true);
+    else if (path)
+        ILQR_LAUNCH_LS(true, false);
+    else if (full)
+        ILQR_LAUNCH_LS(false, true);
+    else
+        ILQR_LAUNCH_LS(false, false);
+#undef ILQR_LAUNCH_LS
     return lrc(hipGetLastError());
 }
 

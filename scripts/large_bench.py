@@ -22,6 +22,8 @@ def main():
     import torch
     from ilqr_amd import _hip
     from ilqr_amd.synthetic import SyntheticWorkload
+    if os.environ.get("ILQR_LIB"):  # A/B of differently compiled builds: ILQR_LIB=build/variant.so
+        _hip.LIB_PATH = os.path.abspath(os.environ["ILQR_LIB"])
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     dev = torch.device("cuda:0")
