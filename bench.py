@@ -335,7 +335,7 @@ def main_large(args):
             line["roofline"]["counters"] = cnt
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(16, os.cpu_count() or 1))
-            n_cpu = 128
+            n_cpu = min(B, 2048)  # ~15 s on 16 cores
             from oracle import c_oracle as co  # the CPU baseline leg: the checker timed as a C port
             Mo = co.synthetic_model(T=TL)
             t1 = time.perf_counter()

@@ -4,6 +4,7 @@ profiles/ and add this workload's entry to profiles/solve_counters.json, the fil
 PMC-derived roofline numbers from.
 
   python scripts/summarise_profiles.py gpurun_out/prof_<tag> <name-prefix> <workload> <batch>
+  python scripts/summarise_profiles.py --bench-line <output of a later bench.py run> profiles/<name>.json
 
 workload: "cartpole" (kernel k_solve) or "large" (kernel k_large_solve).  Per launch of that kernel:
   * average duration                       (--kernel-trace --stats pass)
@@ -19,6 +20,32 @@ import os
 import shutil
 import sys
 from collections import defaultdict
+
+
+def keep_bench_line(log, out):
+    """--bench-line <bench.py output> <profiles/name.json>: keep the JSON line of a bench run as a profile
+    record, REFUSING a line whose live kernel time and whose embedded PMC profile belong to different builds
+    (roofline.kernel_ms vs roofline.counters.kernel_avg_ms more than 3 % apart)."""
+    lines = [ln for ln in open(log) if ln.startswith("{")]
+    if len(lines) != 1:
+        raise SystemExit("%s holds %d JSON lines" % (log, len(lines)))
+    line = json.loads(lines[0])
+    roof = line.get("roofline", {})
+    cnt = roof.get("counters")
+    if cnt is None or not cnt.get("kernel_avg_ms"):
+        raise SystemExit("refused: the line embeds no PMC profile (profiles/solve_counters.json has no entry for it)")
+    live, prof = roof["kernel_ms"], cnt["kernel_avg_ms"]
+    if abs(live - prof) > 0.03 * prof:
+        raise SystemExit("refused: the run's kernel time %.3f ms and the embedded profile's %.3f ms differ by more "
+                         "than 3 %%: collect the profile again from this build" % (live, prof))
+    with open(out, "w") as fh:
+        fh.write(json.dumps(line) + "\n")
+    print("%s: kernel %.3f ms (profile %.3f ms), value %.1f %s" % (out, live, prof, line["value"], line["unit"]))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--bench-line":
+    keep_bench_line(sys.argv[2], sys.argv[3])
+    raise SystemExit(0)
 
 src, prefix, workload, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 kernel_key = {"cartpole": "k_solve", "large": "k_large_solve"}[workload]
