@@ -47,17 +47,39 @@ def test_argument_checks_need_no_gpu():
                                     None, None) == -2
     assert lib.ilqr_solve_workspace_bytes(ctypes.byref(bad.c), 100) == 0
     assert lib.ilqr_boxqp_batched(ctypes.c_int64(1), ctypes.c_int32(9), *([None] * 13)) == -1
-    # large-state path: dimensions other than 32 / 8 have no kernel; missing arrays are argument errors
+    # large-state path: up to 32 states and 8 controls (padded layouts); missing arrays are argument errors
     L = _hip.LargeModelC()
     L.n, L.m, L.T = 32, 8, 20
     assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == 0  # null matrices
     assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -1
-    for name, _ in _hip.LargeModelC._fields_[6:]:
-        setattr(L, name, 4096)  # never dereferenced: the checks below fail first
-    assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == 10 * 8 * (21 * 32 + 20 * 8 + 20 * 8 + 20 * 8 * 32) + 256
+    for name, kind in _hip.LargeModelC._fields_[6:]:
+        if kind is ctypes.c_void_p:
+            setattr(L, name, 4096)  # never dereferenced: the checks below fail first
+    full = 10 * 8 * (21 * 32 + 20 * 8 + 20 * 8 + 20 * 8 * 32) + 256
+    assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == full
     assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(0), None, None, None, None, None) == -1
-    L.n = 16
-    assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -2
+    L.n, L.m = 16, 4  # a smaller model keeps the full-size layouts
+    assert lib.ilqr_large_workspace_bytes(ctypes.byref(L), 10) == full
+    assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -1
+    for n_bad, m_bad in ((33, 8), (32, 9), (0, 8), (32, 0)):
+        L.n, L.m = n_bad, m_bad
+        assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -2
+    L.n, L.m = 32, 8
+    L.goal_stride_x, L.goal_stride_u = 32, 0  # strides come in pairs
+    assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -1
+    L.goal_stride_x, L.goal_stride_u = 31, 8  # a goal does not fit its stride
+    assert lib.ilqr_large_rollout_cost(ctypes.byref(L), ctypes.c_int64(4), None, None, None, None, None) == -1
+    # cart-pole path: per-problem goals are for the solve entry points; the stage entry points refuse them
+    pg = _hip.Model(10, np.eye(5), np.eye(1), lower=[-1.0], upper=[1.0])
+    pg.c.goal_stride_x, pg.c.goal_stride_u = 5, 1
+    assert lib.ilqr_rollout_cost_bm(ctypes.byref(pg.c), ctypes.c_int64(4), ctypes.c_int64(64), None, None, None,
+                                    None, None) == -2
+    assert lib.ilqr_solve_workspace_bytes(ctypes.byref(pg.c), 64) == \
+        lib.ilqr_solve_workspace_bytes(ctypes.byref(_hip.Model(10, np.eye(5), np.eye(1), lower=[-1.0], upper=[1.0]).c), 64) \
+        + 64 * 8 * 6
+    pg.c.goal_stride_u = 0
+    assert lib.ilqr_solve_workspace_bytes(ctypes.byref(pg.c), 64) == 0
+    assert lib.ilqr_version() >= 102
 
 
 def test_reference_import_names():
