@@ -538,13 +538,18 @@ class LargeModel:
     array is uploaded once and kept alive by this object."""
 
     def __init__(self, T, A, B, W, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
-                 dt=0.05, sig_c=2.0, device=None, x_path=None, u_path=None):
+                 dt=0.05, sig_c=2.0, device=None, x_path=None, u_path=None, user=None):
         """A [n, n], B [n, m], W [n, n] with n <= 32 states and m <= 8 controls (the kernels work on 32 x 8; smaller
         models are padded with zeros here, which leaves every result bit the same, see ilqr_large_model).
         x_path [T+1, n], u_path [T, m]: the goals of a PathQRCost instead of x_goal / u_goal.
-        One goal or path per problem: x_goal [B, n], u_goal [B, m] or x_path [B, T+1, n], u_path [B, T, m]."""
+        One goal or path per problem: x_goal [B, n], u_goal [B, m] or x_path [B, T+1, n], u_path [B, T, m].
+        user = (library, params, n, m): the dynamics are those of a per-model library built by
+        ``user_model.build_large_user_model`` (A, B, W are then ignored)."""
         import torch
-        n_real, m_real = int(np.shape(A)[0]), int(np.shape(B)[1])
+        if user is not None:
+            self.lib, n_real, m_real = user[0], int(user[2]), int(user[3])
+        else:
+            n_real, m_real = int(np.shape(A)[0]), int(np.shape(B)[1])
         if not (1 <= n_real <= 32 and 1 <= m_real <= 8):
             raise ValueError("the large-state path holds up to 32 states and 8 controls, not %d and %d" % (n_real, m_real))
         n, m = 32, 8
@@ -560,8 +565,13 @@ class LargeModel:
             return torch.tensor(out, device=dev)
         self.batch_goals = None
         per_problem_goal = x_path is None and x_goal is not None and _ndim(x_goal) == 2
+        if user is not None:  # the model's parameter vector travels in A; B and W are not read
+            p = _host(user[1], (-1,))
+            A, B, W = None, None, None
         self.t = dict(
-            A=up(A, (nr, nr), (n, n)), B=up(B, (nr, mr), (n, m)), W=up(W, (nr, nr), (n, n)), Q=up(Q, (nr, nr), (n, n)),
+            A=torch.tensor(p, device=dev) if user is not None else up(A, (nr, nr), (n, n)),
+            B=None if user is not None else up(B, (nr, mr), (n, m)),
+            W=None if user is not None else up(W, (nr, nr), (n, n)), Q=up(Q, (nr, nr), (n, n)),
             R=up(R, (mr, mr), (m, m)), Q_terminal=up(Q if Q_terminal is None else Q_terminal, (nr, nr), (n, n)),
             x_goal=up(np.zeros(nr) if (x_goal is None or per_problem_goal) else x_goal, (nr,), (n,)),
             u_goal=up(np.zeros(mr) if (u_goal is None or per_problem_goal) else u_goal, (mr,), (m,)),
@@ -592,7 +602,7 @@ class LargeModel:
             self.batch_goals = int(Bg)
             c.goal_stride_x, c.goal_stride_u = n, m
         for name, t in self.t.items():
-            setattr(c, name, t.data_ptr())
+            setattr(c, name, None if t is None else t.data_ptr())
         self.c = c
 
     def subset(self, idx):
@@ -622,13 +632,22 @@ def _check_goal_batch(M, B):
 LARGE_N, LARGE_M = 32, 8  # the sizes the large-state kernels work on (smaller models run zero-padded)
 
 
+def _large_lib(M):
+    """The library that holds the model's kernels: its own (a model compiled from a C source) or the main one."""
+    own = getattr(M, "lib", None)
+    if own is None:
+        return lib()
+    own.ilqr_large_workspace_bytes.restype = C.c_size_t
+    return own
+
+
 def large_rollout_cost(M, x0, us):
     import torch
     B = x0.shape[0]
     x0, us = pad_last(x0, LARGE_N), pad_last(us, LARGE_M)
     xs = torch.empty((B, M.T + 1, LARGE_N), dtype=torch.float64, device=x0.device)
     J = torch.empty(B, dtype=torch.float64, device=x0.device)
-    check(lib().ilqr_large_rollout_cost(C.byref(M.c), C.c_int64(B), _ptr(_req(x0, torch.float64)),
+    check(_large_lib(M).ilqr_large_rollout_cost(C.byref(M.c), C.c_int64(B), _ptr(_req(x0, torch.float64)),
                                         _ptr(_req(us, torch.float64)), _ptr(xs), _ptr(J), _stream()))
     return (xs if M.n == LARGE_N else xs[..., :M.n].contiguous()), J
 
@@ -646,7 +665,7 @@ def large_deriv(M, xs, us, out=None):
     for k, s in shapes.items():
         assert tuple(out[k].shape) == s
         setattr(d, k, _req(out[k], torch.float64).data_ptr())
-    check(lib().ilqr_large_deriv(C.byref(M.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
+    check(_large_lib(M).ilqr_large_deriv(C.byref(M.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
                                  _ptr(_req(us, torch.float64)), C.byref(d), _stream()))
     return out
 
@@ -661,7 +680,7 @@ def large_backward(M, O, xs, us, mu, want_masks=True):
     info = torch.empty((5, B), dtype=torch.int32, device=dev)
     qres = torch.empty((B, M.T), dtype=torch.int32, device=dev) if want_masks else None
     free = torch.empty((B, M.T, LARGE_M), dtype=torch.int32, device=dev) if want_masks else None
-    check(lib().ilqr_large_backward(C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
+    check(_large_lib(M).ilqr_large_backward(C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
                                     _ptr(_req(us, torch.float64)), _ptr(_req(mu, torch.float64)), _ptr(k), _ptr(K),
                                     _ptr(dJ), _ptr(info), _ptr(qres), _ptr(free), _stream()))
     if (M.n, M.m) != (LARGE_N, LARGE_M):
@@ -677,7 +696,7 @@ def large_forward_ls(M, alphas, xs, us, k, K, store_idx=-1):
     J = torch.empty((B, len(al)), dtype=torch.float64, device=dev)
     xs_new = torch.empty_like(xs) if store_idx >= 0 else None
     us_new = torch.empty_like(us) if store_idx >= 0 else None
-    check(lib().ilqr_large_forward_ls(C.byref(M.c), C.c_int64(B), C.c_int32(len(al)), al.ctypes.data_as(_dp),
+    check(_large_lib(M).ilqr_large_forward_ls(C.byref(M.c), C.c_int64(B), C.c_int32(len(al)), al.ctypes.data_as(_dp),
                                       C.c_int32(store_idx), _ptr(_req(xs, torch.float64)),
                                       _ptr(_req(us, torch.float64)), _ptr(_req(k, torch.float64)),
                                       _ptr(_req(K, torch.float64)), _ptr(J), _ptr(xs_new), _ptr(us_new), _stream()))
@@ -704,7 +723,7 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
                mu=torch.ones(B, dtype=torch.float64, device=dev) if mu is None else mu,
                iters=torch.empty(B, dtype=torch.int32, device=dev),
                status=torch.empty(B, dtype=torch.int32, device=dev))
-    need = int(lib().ilqr_large_workspace_bytes(C.byref(M.c), C.c_int64(B)))
+    need = int(_large_lib(M).ilqr_large_workspace_bytes(C.byref(M.c), C.c_int64(B)))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     tr_c, tr = None, None
@@ -717,7 +736,7 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
                 t = torch.full((O.max_iter, B), -1, dtype=torch.int32, device=dev)
             tr[name] = t
             setattr(tr_c, name, t.data_ptr())
-    check(lib().ilqr_large_solve_batched(
+    check(_large_lib(M).ilqr_large_solve_batched(
         C.byref(M.c), C.byref(O.carrying(dJ)), C.c_int64(B), _ptr(_req(x0, torch.float64)), _ptr(_req(us_init, torch.float64)),
         _ptr(_req(delta, torch.float64)), _ptr(_req(k, torch.float64)), _ptr(_req(K, torch.float64)),
         _ptr(res["xs"]), _ptr(res["us"]), _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),

@@ -26,11 +26,38 @@
 
 #include "../../include/ilqr_hip.h"
 
+// A model of the caller's own on this path: compiled with -DILQR_LARGE_USER_MODEL='"model.h"' this file becomes a
+// per-model library (same entry points) whose dynamics are the two functions of the model header -- the contract of
+// include/ilqr_user.h: ILQR_USER_N (<= 32 states), ILQR_USER_M (<= 8 controls; u is a pointer when defined),
+// ILQR_USER_NP parameters, ilqr_user_f(p, x, u, out), ilqr_user_jac(p, x, u, fx [N*N], fu [N*M]) or ILQR_USER_FD.
+// The reference's counterpart is a Dynamics object evaluated once per time step (ilqr/ilqr_dynamics.py:13-91,
+// :94-575).  The model's functions are scalar code: a rollout evaluates f on one lane per step size (16 lanes), a
+// backward step evaluates the Jacobian on one lane into LDS, from where the matrix products take their tiles; the
+// rest of the solver (Q-terms, boxQP, line search) is the MFMA code below.  ilqr_large_model.A then points to the
+// parameter vector (device), B and W are not used.
+#ifdef ILQR_LARGE_USER_MODEL
+#include "ilqr_math.hpp"
+#define ILQR_FN __device__ __forceinline__
+#define ilqr_sincos(x, s, c) ilqr::det_sincos((x), *(s), *(c))
+#define ilqr_atan2(y, x) ilqr::det_atan2((y), (x))
+#define ilqr_sqrt(x) sqrt(x)
+#include ILQR_LARGE_USER_MODEL
+#ifndef ILQR_USER_M
+#define ILQR_USER_M 1
+#endif
+#include "../../include/ilqr_user_fd.h" // ilqr_user_jac by forward differences if the model asks for it
+#endif
+
 namespace {
 
 constexpr int LN = 32; // states
 constexpr int LM = 8;  // controls
 constexpr int LA = 16; // step sizes rolled out together
+#ifdef ILQR_LARGE_USER_MODEL
+constexpr int UN = ILQR_USER_N, UM = ILQR_USER_M;
+static_assert(UN >= 1 && UN <= LN, "ILQR_USER_N must be between 1 and 32 on this path");
+static_assert(UM >= 1 && UM <= LM, "ILQR_USER_M must be between 1 and 8 on this path");
+#endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -702,12 +729,16 @@ __device__ void block_init(BlockMem& M, const LargeP& P, double step_dec)
 {
     for (int i = threadIdx.x; i < LN * LN; i += blockDim.x) {
         int r = i / LN, c = i % LN;
+#ifndef ILQR_LARGE_USER_MODEL
         M.A[r][c] = P.A[i];
         M.W[r][c] = P.W[i];
+#endif
         M.QQ[r][c] = P.Q[i] + P.Q[c * LN + r];
     }
+#ifndef ILQR_LARGE_USER_MODEL
     for (int i = threadIdx.x; i < LN * LM; i += blockDim.x)
         M.fu[i / LM][i % LM] = P.dt * P.B[i];
+#endif
     for (int i = threadIdx.x; i < LM * LM; i += blockDim.x)
         M.RR[i / LM][i % LM] = P.R[i] + P.R[(i % LM) * LM + i / LM];
     for (int i = threadIdx.x; i < LN; i += blockDim.x)
@@ -768,8 +799,10 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 
     // the model matrices come from LDS where they are used; only the small pieces stay in registers
     d4 fu[2][1], RR[1][1], xg[2][1], ug[1][1];
-    fu[0][0] = load_n(&M.fu[0][0], LM + 1, LN, LM, 0, 0, L);
+#ifndef ILQR_LARGE_USER_MODEL
+    fu[0][0] = load_n(&M.fu[0][0], LM + 1, LN, LM, 0, 0, L); // dt B: the same at every step
     fu[1][0] = load_n(&M.fu[0][0], LM + 1, LN, LM, 1, 0, L);
+#endif
     RR[0][0] = load_n(&M.RR[0][0], LM, LM, LM, 0, 0, L);
     xg[0][0] = load_v(P.xg, LN, 0, L);
     xg[1][0] = load_v(P.xg, LN, 1, L);
@@ -808,6 +841,31 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         xv[1][0] = load_v(xs + (size_t)i * LN, LN, 1, L);
         uv[0][0] = load_v(us + (size_t)i * LM, LM, 0, L);
 
+#ifdef ILQR_LARGE_USER_MODEL
+        // f_x, f_u of the caller's model at (x_i, u_i): one lane evaluates its Jacobian function into LDS (row-major
+        // [n][n] and [n][m], as the model writes them), the matrix products take their tiles from there
+        d4 fx[2][2];
+        store_v(S.vx, LN, 0, xv[0][0], L);
+        store_v(S.vx, LN, 1, xv[1][0], L);
+        store_v(S.x, LM, 0, uv[0][0], L);
+        wave_sync();
+        if (lane == 0) {
+#if ILQR_USER_M > 1
+            ilqr_user_jac(P.A, S.vx, S.x, &S.Vn[0][0], &S.K[0][0]);
+#else
+            ilqr_user_jac(P.A, S.vx, S.x[0], &S.Vn[0][0], &S.K[0][0]);
+#endif
+        }
+        wave_sync();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                fx[rt][ct] = load_n(&S.Vn[0][0], UN, UN, UN, rt, ct, L);
+            fu[rt][0] = load_n(&S.K[0][0], UM, UN, UM, rt, 0, L);
+        }
+        wave_sync(); // (the two buffers are rewritten below: f_x is parked in S.Vn, the gains go to S.K)
+#else
         // z = W x, g_i = c phi'(z_i), f_x = I + dt (A + diag(g) W)
         d4 fx[2][2];
         {
@@ -838,6 +896,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
                 }
             }
         }
+#endif
         // Q_u = l_u + f_u^T V_x                                   (:207, ilqr_cost.py:571-587)
         d4 Qu[1][1];
         {
@@ -1085,12 +1144,16 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
         for (int ct = 0; ct < 2; ++ct) {
             Qn[rt][ct] = load_n(P.Q, LN, LN, LN, rt, ct, L);
             Qtn[rt][ct] = load_n(P.Qt, LN, LN, LN, rt, ct, L);
+#ifndef ILQR_LARGE_USER_MODEL
             WT[rt][ct] = load_nt(P.W, LN, LN, LN, rt, ct, L);
             AT[rt][ct] = load_nt(P.A, LN, LN, LN, rt, ct, L);
+#endif
         }
     Rn[0][0] = load_n(P.R, LM, LM, LM, 0, 0, L);
+#ifndef ILQR_LARGE_USER_MODEL
     BT[0][0] = load_nt(P.B, LM, LN, LM, 0, 0, L); // B^T [8][32]
     BT[0][1] = load_nt(P.B, LM, LN, LM, 0, 1, L);
+#endif
     d4 xg[2], ug = load_v(P.ug, LM, 0, L);
     xg[0] = load_v(P.xg, LN, 0, L);
     xg[1] = load_v(P.xg, LN, 1, L);
@@ -1168,6 +1231,41 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
                 if (diag_lane[r])
                     J = J + (PATH ? sx[0][0][r] + su[0][0][r] : sx[0][0][r] * 0.5 + su[0][0][r] * 0.5);
         }
+#ifdef ILQR_LARGE_USER_MODEL
+        // x+ = f(x, u) of the caller's model: the 16 candidate states go through LDS as 16 plain vectors, lane c
+        // evaluates the model for candidate c, and the results return to the matrix layout
+        {
+            double* xb = &S.P1[0][0];  // [16][LN]
+            double* ub = &S.Qux[0][0]; // [16][LM]
+            double* ob = &S.Vn[0][0];  // [16][LN]
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xb[L.c * LN + 16 * rt + L.g + 4 * r] = Xh[rt][0][r];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                ub[L.c * LM + L.g + 4 * r] = Uh[0][0][r];
+            wave_sync();
+            if (lane < LA) {
+#if ILQR_USER_M > 1
+                ilqr_user_f(P.A, xb + lane * LN, ub + lane * LM, ob + lane * LN);
+#else
+                ilqr_user_f(P.A, xb + lane * LN, ub[lane * LM], ob + lane * LN);
+#endif
+            }
+            wave_sync();
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + L.g + 4 * r;
+                    Xh[rt][0][r] = row < UN ? ob[L.c * LN + row] : 0.0;
+                }
+            wave_sync(); // the buffers are rewritten by the next step
+        }
+#else
         // x+ = x + dt (A x + B u + c phi(W x))
         {
             d4 z[2][1], axv[2][1], bu[2][1];
@@ -1184,6 +1282,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
                     Xh[rt][0][r] = Xh[rt][0][r] + P.dt * ((axv[rt][0][r] + bu[rt][0][r]) + P.sig_c * phi);
                 }
         }
+#endif
     }
     if (store_col >= 0 && L.c == store_col) {
 #pragma unroll
@@ -1573,11 +1672,18 @@ int large_check(const ilqr_large_model* m)
 {
     if (!m)
         return ILQR_ERR_ARG;
+#ifdef ILQR_LARGE_USER_MODEL
+    if (m->n != UN || m->m != UM) // the library was compiled around a model of these dimensions
+        return ILQR_ERR_UNSUPPORTED;
+    if (m->T < 1 || !m->A || !m->Q || !m->R || !m->Q_terminal || !m->x_goal || !m->u_goal || !m->lower || !m->upper)
+        return ILQR_ERR_ARG; // (A: the model's parameter vector; B and W are not used)
+#else
     if (m->n < 1 || m->n > LN || m->m < 1 || m->m > LM)
         return ILQR_ERR_UNSUPPORTED;
     if (m->T < 1 || !m->A || !m->B || !m->W || !m->Q || !m->R || !m->Q_terminal || !m->x_goal || !m->u_goal ||
         !m->lower || !m->upper)
         return ILQR_ERR_ARG;
+#endif
     if (m->cost_kind != ILQR_COST_QR && m->cost_kind != ILQR_COST_PATH_QR)
         return ILQR_ERR_UNSUPPORTED;
     if ((m->goal_stride_x != 0) != (m->goal_stride_u != 0))
@@ -1665,6 +1771,9 @@ int ilqr_large_deriv(const ilqr_large_model* model, int64_t B, const double* xs,
     int rc = large_check(model);
     if (rc != ILQR_OK)
         return rc;
+#ifdef ILQR_LARGE_USER_MODEL
+    return ILQR_ERR_UNSUPPORTED; // the derivative stream is the built-in model's
+#endif
     if (B < 1 || !xs || !us || !out || !out->fx || !out->fu || !out->lx || !out->lu || !out->lxx || !out->luu ||
         !out->lux || !out->lxT || !out->lxxT)
         return ILQR_ERR_ARG;
@@ -1740,6 +1849,19 @@ int ilqr_large_debug_qp_phases(unsigned long long* host8, int reset)
     if (reset)
         return lrc(hipMemcpyToSymbol(HIP_SYMBOL(g_lqp), z, sizeof(z)));
     return lrc(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_lqp), sizeof(z)));
+}
+#endif
+
+#ifdef ILQR_LARGE_USER_MODEL
+/* The dimensions the library was compiled for (states, controls, parameters). */
+int ilqr_large_user_dims(int32_t* n, int32_t* m, int32_t* n_params)
+{
+    if (!n || !m || !n_params)
+        return ILQR_ERR_ARG;
+    *n = UN;
+    *m = UM;
+    *n_params = ILQR_USER_NP;
+    return ILQR_OK;
 }
 #endif
 

@@ -52,7 +52,7 @@ class iLQR(BaseTrajOptimizer):
         self.N = int(time_steps)
         self.control_limit = control_limit
 
-        if getattr(sys_dynamics, "device_model", None) not in ("cartpole", "sigmoid32", "user"):
+        if getattr(sys_dynamics, "device_model", None) not in ("cartpole", "sigmoid32", "user", "large_user"):
             raise NotImplementedError(
                 "iLQR on the GPU needs a dynamics model with a device implementation "
                 "(ilqr_amd.cartpole.CartPoleDynamics, ilqr_amd.synthetic.SigmoidLinearDynamics, or a C model "
@@ -104,6 +104,14 @@ class iLQR(BaseTrajOptimizer):
                                             self.lower_bound, self.upper_bound, x_path=x_path, u_path=u_path)
             return user_model.UserModel(d.lib, self.N, d.params, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal,
                                         self.lower_bound, self.upper_bound)
+        if d.device_model == "large_user":
+            from . import user_model
+            if isinstance(c, PathQRCost):
+                return user_model.LargeUserModel(d.lib, self.N, d.params, c.Q, c.R, c.Q_terminal, None, None,
+                                                 self.lower_bound, self.upper_bound, x_path=c.x_path, u_path=c.u_path,
+                                                 device=self._device())
+            return user_model.LargeUserModel(d.lib, self.N, d.params, c.Q, c.R, c.Q_terminal, c.x_goal, c.u_goal,
+                                             self.lower_bound, self.upper_bound, device=self._device())
         if d.device_model == "sigmoid32":
             # the device copy of the model (ten uploads) is kept while nothing it was built from has changed
             path = isinstance(c, PathQRCost)

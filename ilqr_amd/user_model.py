@@ -127,6 +127,79 @@ class UserModel(object):
         return other
 
 
+# ---- models with more than 8 states: the large-state path compiled around the same kind of header
+
+_LARGE_TU = os.path.join(_HERE, "csrc", "ilqr_large.hip")
+
+
+def large_library_path(name):
+    return os.path.join(_HERE, "libilqr_largeuser_%s.so" % name)
+
+
+def build_large_user_model(header, name, force=False):
+    """Compile the large-state solver (one problem per wavefront, up to 32 states and 8 controls) around the
+    model header ``header`` (same contract as ``build_user_model``; hipcc, gfx950; needs no GPU)."""
+    header = os.path.abspath(header)
+    out = large_library_path(name)
+    deps = [_LARGE_TU, header, os.path.join(_HERE, "csrc", "ilqr_math.hpp"),
+            os.path.join(_HERE, "..", "include", "ilqr_hip.h"), os.path.join(_HERE, "..", "include", "ilqr_user_fd.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc] + HIPCC_FLAGS + ["-DILQR_LARGE_USER_MODEL=\"%s\"" % header, _LARGE_TU, "-o", out], check=True)
+    return out
+
+
+def load_large(name):
+    path = large_library_path(name)
+    if not os.path.exists(path):
+        raise _hip.IlqrHipError("%s is missing: build it with ilqr_amd.user_model.build_large_user_model(header, %r)"
+                                % (path, name))
+    lib = C.CDLL(path)
+    lib.ilqr_large_workspace_bytes.restype = C.c_size_t
+    return lib
+
+
+def large_user_dims(lib):
+    n, m, npar = C.c_int32(), C.c_int32(), C.c_int32()
+    _hip.check(lib.ilqr_large_user_dims(C.byref(n), C.byref(m), C.byref(npar)))
+    return n.value, m.value, npar.value
+
+
+def LargeUserModel(lib, T, params, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
+                   x_path=None, u_path=None, device=None):
+    """The device model (an ``_hip.LargeModel``) of a library built by ``build_large_user_model``: every
+    ``_hip.large_*`` wrapper then runs that library's kernels."""
+    n, m, npar = large_user_dims(lib)
+    params = np.asarray(params, dtype=np.float64).reshape(npar)
+    return _hip.LargeModel(T, None, None, None, Q, R, Q_terminal, x_goal, u_goal, lower, upper, device=device,
+                           x_path=x_path, u_path=u_path, user=(lib, params, n, m))
+
+
+class LargeUserDynamics(Dynamics):
+    """A ``Dynamics`` with more than 8 states (up to 32, with up to 8 controls) backed by a per-model library of the
+    large-state path (``build_large_user_model(header, name)``); arguments as ``UserDynamics``."""
+
+    device_model = "large_user"
+
+    def __init__(self, name, params, max_control):
+        self.name = name
+        self.lib = load_large(name)
+        self._n, self._m, npar = large_user_dims(self.lib)
+        self.params = np.asarray(params, dtype=np.float64).reshape(npar)
+        self.upper_bound = np.broadcast_to(np.asarray(max_control, dtype=np.float64), (self._m,)).copy()
+        self.lower_bound = -self.upper_bound
+
+    state_dimension = property(lambda self: self._n)
+    control_dimension = property(lambda self: self._m)
+    has_hessians = property(lambda self: False)
+
+    def f(self, x, u, i):
+        raise NotImplementedError("point evaluations of a user model are not exported by its library")
+
+    f_x = f_u = f
+
+
 def load(name):
     path = library_path(name)
     if not os.path.exists(path):

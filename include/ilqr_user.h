@@ -19,7 +19,16 @@
  * ilqr_amd/csrc/ilqr_user_tu.hip is compiled around it into one shared library per model
  * (ilqr_amd.user_model.build_user_model does that with hipcc).  That library exports the
  * functions below; everything else (options, trace, array layouts, per-problem status)
- * is as for ilqr_solve_batched in ilqr_hip.h. */
+ * is as for ilqr_solve_batched in ilqr_hip.h.
+ *
+ * Models with MORE than 8 states or 4 controls (up to 32 states and 8 controls) use the same
+ * header contract but are compiled into the large-state path instead:
+ * ilqr_amd/csrc/ilqr_large.hip with -DILQR_LARGE_USER_MODEL='"model.h"'
+ * (ilqr_amd.user_model.build_large_user_model).  That library exports the ilqr_large_* entry
+ * points declared in ilqr_hip.h -- ilqr_large_model.A then points to the model's parameter
+ * vector (DEVICE, ILQR_USER_NP doubles), B and W are not used, n and m must equal the model's --
+ * and  int ilqr_large_user_dims(int32_t* n, int32_t* m, int32_t* n_params).  ilqr_large_deriv
+ * returns ILQR_ERR_UNSUPPORTED there. */
 #ifndef ILQR_USER_H
 #define ILQR_USER_H
 
