@@ -221,3 +221,50 @@ def test_user_model_libraries_export_every_declared_symbol():
         n, npar = C.c_int32(), C.c_int32()
         assert lib.ilqr_user_dims(C.byref(n), C.byref(npar)) == 0 and (n.value, npar.value) == dims
         assert lib.ilqr_user_controls() == {"planar_rotor_user": 2, "planar_rotor_fd_user": 2, "mass_chain_user": 4}.get(name, 1)
+
+
+def test_large_user_model_library_and_its_jacobian():
+    """A model with more than 8 states: the per-model build of the large-state path exports the ilqr_large_*
+    entry points (loading needs no GPU) and refuses other dimensions; the model's Jacobian agrees with central
+    differences of its f, and the oracle's solve on it descends."""
+    import ctypes as C
+    import re
+    from ilqr_amd import _hip, user_model as um
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    um.build_large_user_model(os.path.join(MODELS, "long_chain_user.h"), "long_chain_user")
+    lib = C.CDLL(um.large_library_path("long_chain_user"))
+    header = open(os.path.join(root, "include", "ilqr_hip.h")).read()
+    declared = set(re.findall(r"\b(ilqr_large_[a-z0-9_]+)\s*\(", header)) - {"ilqr_large_model"}
+    assert {"ilqr_large_solve_batched", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_rollout_cost",
+            "ilqr_large_workspace_bytes"} <= declared
+    for sym in declared | {"ilqr_large_user_dims"}:
+        assert hasattr(lib, sym), sym
+    assert um.large_user_dims(lib) == (20, 5, 4)
+    L = _hip.LargeModelC()
+    L.n, L.m, L.T = 32, 8, 10  # not this library's model
+    assert lib.ilqr_large_rollout_cost(C.byref(L), C.c_int64(4), None, None, None, None, None) == -2
+    L.n, L.m = 20, 5
+    assert lib.ilqr_large_rollout_cost(C.byref(L), C.c_int64(4), None, None, None, None, None) == -1  # null arrays
+    # the model source itself, on the CPU
+    olib = co.build_user_model(os.path.join(MODELS, "long_chain_user.h"), "long_chain_user")
+    p = np.array([0.05, 4.0, 6.0, 0.3])
+    Mo = co.user_model(olib, p, 20, np.eye(20), 0.2 * np.eye(5), 10.0 * np.eye(20), None, None, [-1.5] * 5, [1.5] * 5)
+    r = np.random.RandomState(3)
+    x, u = r.uniform(-1, 1, 20), r.uniform(-1, 1, 5)
+    f0, fx, fu = co.dynamics(Mo, x, u)
+    h = 1e-6
+    for j in range(20):
+        d = np.zeros(20)
+        d[j] = h
+        num = (co.dynamics(Mo, x + d, u)[0][0] - co.dynamics(Mo, x - d, u)[0][0]) / (2 * h)
+        assert np.allclose(fx[0][:, j], num, atol=1e-7)
+    for j in range(5):
+        d = np.zeros(5)
+        d[j] = h
+        num = (co.dynamics(Mo, x, u + d)[0][0] - co.dynamics(Mo, x, u - d)[0][0]) / (2 * h)
+        assert np.allclose(fu[0][:, j], num, atol=1e-7)
+    x0 = r.uniform(-0.5, 0.5, (3, 20))
+    us0 = r.uniform(-0.5, 0.5, (3, 20, 5))
+    out = co.solve(Mo, co.Opts(max_iter=10), x0, us0)
+    J0 = co.rollout_cost(Mo, x0, us0)[1]
+    assert (out["J"] < J0).all()
