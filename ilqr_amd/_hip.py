@@ -73,6 +73,7 @@ EXPORTS = (
     "ilqr_cartpole_plant_step", "ilqr_detmath", "ilqr_debug_wave_log",
     "ilqr_large_rollout_cost", "ilqr_large_deriv", "ilqr_large_backward", "ilqr_large_forward_ls", "ilqr_large_workspace_bytes",
     "ilqr_large_solve_batched", "ilqr_large_debug_profile", "ilqr_cartpole_mpc_advance",
+    "ilqr_xl_rollout_cost", "ilqr_xl_backward", "ilqr_xl_forward_ls", "ilqr_xl_workspace_bytes", "ilqr_xl_solve_batched",
 )
 
 _lib = None
@@ -97,6 +98,8 @@ def lib():
         L.ilqr_solve_workspace_bytes.argtypes = [C.POINTER(ModelC), C.c_int64]
         L.ilqr_large_workspace_bytes.restype = C.c_size_t
         L.ilqr_large_workspace_bytes.argtypes = [C.POINTER(LargeModelC), C.c_int64]
+        L.ilqr_xl_workspace_bytes.restype = C.c_size_t
+        L.ilqr_xl_workspace_bytes.argtypes = [C.POINTER(LargeModelC), C.c_int64]
         _lib = L
     return _lib
 
@@ -533,6 +536,10 @@ def pad_last(t, size, dims=1):
     return out
 
 
+LARGE_N, LARGE_M = 32, 8  # the sizes the register-resident kernels work on (smaller models run zero-padded)
+XL_N, XL_M = 64, 16       # the largest model of the LDS-resident kernels
+
+
 class LargeModel:
     """Synthetic model x+ = x + dt (A x + B u + c phi(W x)) with a QRCost and box limits; every
     array is uploaded once and kept alive by this object."""
@@ -550,9 +557,16 @@ class LargeModel:
             self.lib, n_real, m_real = user[0], int(user[2]), int(user[3])
         else:
             n_real, m_real = int(np.shape(A)[0]), int(np.shape(B)[1])
-        if not (1 <= n_real <= 32 and 1 <= m_real <= 8):
-            raise ValueError("the large-state path holds up to 32 states and 8 controls, not %d and %d" % (n_real, m_real))
-        n, m = 32, 8
+        if not (1 <= n_real <= XL_N and 1 <= m_real <= XL_M):
+            raise ValueError("the large-state paths hold up to %d states and %d controls, not %d and %d"
+                             % (XL_N, XL_M, n_real, m_real))
+        # up to 32 x 8: the register-resident kernels, which work on 32 x 8 (smaller models zero-padded);
+        # beyond: the LDS-resident kernels (ilqr_xl_*), dense arrays of the model's own size
+        self.xl = n_real > LARGE_N or m_real > LARGE_M
+        if self.xl and user is not None:
+            raise ValueError("per-model libraries hold up to 32 states and 8 controls")
+        n, m = (n_real, m_real) if self.xl else (LARGE_N, LARGE_M)
+        self.full = (n, m)
         self.n, self.m, self.T = n_real, m_real, int(T)
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
 
@@ -629,9 +643,6 @@ def _check_goal_batch(M, B):
                          "model of a sub-batch)" % (M.batch_goals, B))
 
 
-LARGE_N, LARGE_M = 32, 8  # the sizes the large-state kernels work on (smaller models run zero-padded)
-
-
 def _large_lib(M):
     """The library that holds the model's kernels: its own (a model compiled from a C source) or the main one."""
     own = getattr(M, "lib", None)
@@ -641,15 +652,26 @@ def _large_lib(M):
     return own
 
 
+def _large_fn(M, name):
+    """The entry point `name` of the family that holds the model: ilqr_large_* (up to 32 x 8, zero-padded layout) or
+    ilqr_xl_* (up to 64 x 16, dense layout)."""
+    return getattr(_large_lib(M), ("ilqr_xl_" if getattr(M, "xl", False) else "ilqr_large_") + name)
+
+
+def _large_full(M):
+    return getattr(M, "full", (LARGE_N, LARGE_M))
+
+
 def large_rollout_cost(M, x0, us):
     import torch
     B = x0.shape[0]
-    x0, us = pad_last(x0, LARGE_N), pad_last(us, LARGE_M)
-    xs = torch.empty((B, M.T + 1, LARGE_N), dtype=torch.float64, device=x0.device)
+    FN, FM = _large_full(M)
+    x0, us = pad_last(x0, FN), pad_last(us, FM)
+    xs = torch.empty((B, M.T + 1, FN), dtype=torch.float64, device=x0.device)
     J = torch.empty(B, dtype=torch.float64, device=x0.device)
-    check(_large_lib(M).ilqr_large_rollout_cost(C.byref(M.c), C.c_int64(B), _ptr(_req(x0, torch.float64)),
+    check(_large_fn(M, "rollout_cost")(C.byref(M.c), C.c_int64(B), _ptr(_req(x0, torch.float64)),
                                         _ptr(_req(us, torch.float64)), _ptr(xs), _ptr(J), _stream()))
-    return (xs if M.n == LARGE_N else xs[..., :M.n].contiguous()), J
+    return (xs if M.n == FN else xs[..., :M.n].contiguous()), J
 
 
 def large_deriv(M, xs, us, out=None):
@@ -673,17 +695,18 @@ def large_deriv(M, xs, us, out=None):
 def large_backward(M, O, xs, us, mu, want_masks=True):
     import torch
     B, dev = xs.shape[0], xs.device
-    xs, us = pad_last(xs, LARGE_N), pad_last(us, LARGE_M)
-    k = torch.empty((B, M.T, LARGE_M), dtype=torch.float64, device=dev)
-    K = torch.empty((B, M.T, LARGE_M, LARGE_N), dtype=torch.float64, device=dev)
+    FN, FM = _large_full(M)
+    xs, us = pad_last(xs, FN), pad_last(us, FM)
+    k = torch.empty((B, M.T, FM), dtype=torch.float64, device=dev)
+    K = torch.empty((B, M.T, FM, FN), dtype=torch.float64, device=dev)
     dJ = torch.empty((2, B), dtype=torch.float64, device=dev)
     info = torch.empty((5, B), dtype=torch.int32, device=dev)
     qres = torch.empty((B, M.T), dtype=torch.int32, device=dev) if want_masks else None
-    free = torch.empty((B, M.T, LARGE_M), dtype=torch.int32, device=dev) if want_masks else None
-    check(_large_lib(M).ilqr_large_backward(C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
+    free = torch.empty((B, M.T, FM), dtype=torch.int32, device=dev) if want_masks else None
+    check(_large_fn(M, "backward")(C.byref(M.c), C.byref(O.c), C.c_int64(B), _ptr(_req(xs, torch.float64)),
                                     _ptr(_req(us, torch.float64)), _ptr(_req(mu, torch.float64)), _ptr(k), _ptr(K),
                                     _ptr(dJ), _ptr(info), _ptr(qres), _ptr(free), _stream()))
-    if (M.n, M.m) != (LARGE_N, LARGE_M):
+    if (M.n, M.m) != (FN, FM):
         k, K = k[..., :M.m].contiguous(), K[..., :M.m, :M.n].contiguous()
         free = None if free is None else free[..., :M.m].contiguous()
     return dict(k=k, K=K, dJ=dJ, info=info, qp_result=qres, free=free)
@@ -696,7 +719,7 @@ def large_forward_ls(M, alphas, xs, us, k, K, store_idx=-1):
     J = torch.empty((B, len(al)), dtype=torch.float64, device=dev)
     xs_new = torch.empty_like(xs) if store_idx >= 0 else None
     us_new = torch.empty_like(us) if store_idx >= 0 else None
-    check(_large_lib(M).ilqr_large_forward_ls(C.byref(M.c), C.c_int64(B), C.c_int32(len(al)), al.ctypes.data_as(_dp),
+    check(_large_fn(M, "forward_ls")(C.byref(M.c), C.c_int64(B), C.c_int32(len(al)), al.ctypes.data_as(_dp),
                                       C.c_int32(store_idx), _ptr(_req(xs, torch.float64)),
                                       _ptr(_req(us, torch.float64)), _ptr(_req(k, torch.float64)),
                                       _ptr(_req(K, torch.float64)), _ptr(J), _ptr(xs_new), _ptr(us_new), _stream()))
@@ -707,7 +730,7 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
     import torch
     B, dev = x0.shape[0], x0.device
     _check_goal_batch(M, B)
-    T, n, m = M.T, LARGE_N, LARGE_M
+    T, (n, m) = M.T, _large_full(M)
     padded = (M.n, M.m) != (n, m)
     delta = torch.full((B,), 2.0, dtype=torch.float64, device=dev) if delta is None else delta
     k_in, K_in = k, K
@@ -723,7 +746,7 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
                mu=torch.ones(B, dtype=torch.float64, device=dev) if mu is None else mu,
                iters=torch.empty(B, dtype=torch.int32, device=dev),
                status=torch.empty(B, dtype=torch.int32, device=dev))
-    need = int(_large_lib(M).ilqr_large_workspace_bytes(C.byref(M.c), C.c_int64(B)))
+    need = int(_large_fn(M, "workspace_bytes")(C.byref(M.c), C.c_int64(B)))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     tr_c, tr = None, None
@@ -736,7 +759,7 @@ def large_solve(M, O, x0, us_init, delta=None, k=None, K=None, trace=False, work
                 t = torch.full((O.max_iter, B), -1, dtype=torch.int32, device=dev)
             tr[name] = t
             setattr(tr_c, name, t.data_ptr())
-    check(_large_lib(M).ilqr_large_solve_batched(
+    check(_large_fn(M, "solve_batched")(
         C.byref(M.c), C.byref(O.carrying(dJ)), C.c_int64(B), _ptr(_req(x0, torch.float64)), _ptr(_req(us_init, torch.float64)),
         _ptr(_req(delta, torch.float64)), _ptr(_req(k, torch.float64)), _ptr(_req(K, torch.float64)),
         _ptr(res["xs"]), _ptr(res["us"]), _ptr(res["J"]), _ptr(res["mu"]), _ptr(res["iters"]), _ptr(res["status"]),

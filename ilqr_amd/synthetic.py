@@ -22,7 +22,7 @@ class SigmoidLinearDynamics(Dynamics):
         self.W = np.array(W, dtype=np.float64)
         n, m = self.A.shape[0], self.B.shape[1]
         assert self.A.shape == (n, n) and self.W.shape == (n, n) and self.B.shape == (n, m), "A, W [n, n], B [n, m]"
-        assert 1 <= n <= 32 and 1 <= m <= 8, "the device model holds up to 32 states and 8 controls"
+        assert 1 <= n <= 64 and 1 <= m <= 16, "the device model holds up to 64 states and 16 controls"
         self.tau = float(dt)
         self.sig_c = float(sig_c)
         self.upper_bound = np.full(m, float(max_control))

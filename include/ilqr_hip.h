@@ -336,6 +336,31 @@ int ilqr_large_solve_batched(const ilqr_large_model* model, const ilqr_opts* opt
                              double* J, double* mu, int32_t* iters, int32_t* status, const ilqr_trace* trace,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- wide path: up to 64 states and 16 controls, one problem per workgroup, matrices resident in LDS ----
+ *
+ * The reference's sweep is dimension-agnostic (ilqr_core.py:109-228); these entry points run it for models too
+ * large for a wavefront's registers: the same struct, the same synthetic model family and cost kinds, the same
+ * per-problem goals, with 1 <= n <= 64 and 1 <= m <= 16.  DENSE layout: every array has the model's own size
+ * (A [n*n], B [n*m], R [m*m], x_goal [n], ...; trajectories [B,T+1,n], [B,T,m]; gains [B,T,m,n]) -- no padding.
+ * Semantics and outputs of each call are those of its ilqr_large_* namesake; results are bit-identical to it
+ * where both apply (n <= 32, m <= 8). */
+int ilqr_xl_rollout_cost(const ilqr_large_model* model, int64_t B, const double* x0, const double* us, double* xs,
+                         double* J, void* stream);
+int ilqr_xl_backward(const ilqr_large_model* model, const ilqr_opts* opts, int64_t B, const double* xs,
+                     const double* us, const double* mu, double* k, double* K, double* dJ, int32_t* info,
+                     int32_t* qp_result, int32_t* free_mask, void* stream);
+int ilqr_xl_forward_ls(const ilqr_large_model* model, int64_t B, int32_t n_alpha, const double* alphas,
+                       int32_t store_idx, const double* xs, const double* us, const double* k, const double* K,
+                       double* J_new, double* xs_new, double* us_new, void* stream);
+/* iLQR.update_u (ilqr_core.py:241-399), arguments as ilqr_large_solve_batched.  The workspace holds, per resident
+ * workgroup (one per CU, or B if fewer), four candidate trajectories of the line search (four step sizes are
+ * rolled out at a time, one per wavefront, and scanned in the reference's order) and a second copy of the gains. */
+size_t ilqr_xl_workspace_bytes(const ilqr_large_model* model, int64_t B);
+int ilqr_xl_solve_batched(const ilqr_large_model* model, const ilqr_opts* opts, int64_t B, const double* x0,
+                          const double* us_init, double* delta, double* k, double* K, double* xs, double* us,
+                          double* J, double* mu, int32_t* iters, int32_t* status, const ilqr_trace* trace,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,8 +42,8 @@
 
 #include "det_math.h"
 
-#define NMAX 32
-#define MMAX 8
+#define NMAX 64
+#define MMAX 16
 
 enum { MODEL_CARTPOLE = 0, MODEL_LINEAR = 1, MODEL_SIGMOID = 2, MODEL_USER = 3 };
 
