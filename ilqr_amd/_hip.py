@@ -545,13 +545,15 @@ class LargeModel:
     array is uploaded once and kept alive by this object."""
 
     def __init__(self, T, A, B, W, Q, R, Q_terminal=None, x_goal=None, u_goal=None, lower=None, upper=None,
-                 dt=0.05, sig_c=2.0, device=None, x_path=None, u_path=None, user=None):
+                 dt=0.05, sig_c=2.0, device=None, x_path=None, u_path=None, user=None, wide=False):
         """A [n, n], B [n, m], W [n, n] with n <= 32 states and m <= 8 controls (the kernels work on 32 x 8; smaller
         models are padded with zeros here, which leaves every result bit the same, see ilqr_large_model).
         x_path [T+1, n], u_path [T, m]: the goals of a PathQRCost instead of x_goal / u_goal.
         One goal or path per problem: x_goal [B, n], u_goal [B, m] or x_path [B, T+1, n], u_path [B, T, m].
         user = (library, params, n, m): the dynamics are those of a per-model library built by
-        ``user_model.build_large_user_model`` (A, B, W are then ignored)."""
+        ``user_model.build_large_user_model`` (A, B, W are then ignored).
+        Models with more than 32 states or 8 controls (up to 64 and 16) run on the LDS-resident kernels
+        (ilqr_xl_*), dense arrays; ``wide=True`` puts a smaller model there as well (same results)."""
         import torch
         if user is not None:
             self.lib, n_real, m_real = user[0], int(user[2]), int(user[3])
@@ -562,7 +564,7 @@ class LargeModel:
                              % (XL_N, XL_M, n_real, m_real))
         # up to 32 x 8: the register-resident kernels, which work on 32 x 8 (smaller models zero-padded);
         # beyond: the LDS-resident kernels (ilqr_xl_*), dense arrays of the model's own size
-        self.xl = n_real > LARGE_N or m_real > LARGE_M
+        self.xl = bool(wide) or n_real > LARGE_N or m_real > LARGE_M
         if self.xl and user is not None:
             raise ValueError("per-model libraries hold up to 32 states and 8 controls")
         n, m = (n_real, m_real) if self.xl else (LARGE_N, LARGE_M)
