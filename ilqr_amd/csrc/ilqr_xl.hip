@@ -71,19 +71,27 @@ struct XlSolveOpts {
 
 // ---- LDS of one workgroup = one problem ----------------------------------------------------------------------
 
-struct XlBw { // a backward sweep
+constexpr int XTAB = 512; // Armijo step sizes tabulated per sweep (the loop's own repeated multiplications)
+
+// A backward sweep.  INVARIANT: every matrix below holds exact zeros outside its rows x cols (the sweep starts by
+// zeroing everything and every store is guarded), so the MFMA operands are read without bounds checks: what lies
+// outside a matrix appends fma(0, 0, s) == s to the end of a chain (s may be anything, NaN included).
+struct XlBw {
     double Vxx[XN * LDN], fx[XN * LDN];
     double M1[XN * LDN]; // f_x^T V_xx; later in the step the unsymmetrised V_xx
     double fu[XN * LDM];
-    union {
-        double M2[XM * LDN]; // f_u^T (V_xx + mu I)
-        double T1[XN * LDM]; // K^T Q_uu (after Q_ux and Q_uu have been formed from M2)
-    };
+    double M2[XM * LDN];  // f_u^T (V_xx + mu I)
+    double T1[XN * LDM];  // K^T Q_uu
     double Qux[XM * LDN], Kl[XM * LDN];
     double H[XM * LDM];  // Q_uu
-    double Lf[XM * LDM]; // Cholesky factor: of Q_uu for the warm start, then boxQP's H_ff (rows/columns of the free set)
-    double x[XN], xd[XN], lx[XN], gi[XN], Vx[XN], Qx[XN];
-    double u[XM], ud[XM], lu[XM], Qu[XM], lo[XM], hi[XM], qx[XM], grad[XM], srch[XM], rd[XM], qa[XM];
+    double steps[XTAB];
+    // operands of a step, written one step ahead by wavefronts 1..3 while wavefront 0 runs boxQP: two sets, used in
+    // turn by the parity of the step
+    double xd[2][XN], lx[2][XN];
+    double ud[2][XM], lu[2][XM], lo[2][XM], hi[2][XM];
+    double xw[3][XN], gi[3][XN]; // per wavefront 1..3: its own copy of x and of c phi'(W x)
+    double Vx[XN], Qx[XN];
+    double Qu[XM], qx[XM], grad[XM];
 };
 
 struct XlFwWave { // a rollout of one wavefront
@@ -108,6 +116,17 @@ struct XlMem {
 
 static_assert(sizeof(XlMem) <= 160 * 1024, "one problem's matrices must fit the LDS of a CU");
 
+#ifdef ILQR_XL_PROF // diagnostic build only: shader clocks of wavefront 0 per phase of a backward step, summed
+static __device__ unsigned long long g_xl_prof[16];
+#define XP_T(var) const long long var = clock64()
+#define XP_ADD(slot, a, b)                                                       \
+    if ((threadIdx.x & 255) == 0)                                                \
+    atomicAdd(&g_xl_prof[slot], (unsigned long long)((b) - (a)))
+#else
+#define XP_T(var)
+#define XP_ADD(slot, a, b)
+#endif
+
 __device__ __forceinline__ void xl_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -123,31 +142,51 @@ __device__ __forceinline__ double xl_clamp(double lo, double hi, double v)
 
 // ---- matrix products out of LDS ----------------------------------------------------------------------------------
 
-struct XlMat { // logical element (r, c): p[r * ld + c], or p[c * ld + r] when tr; zero outside rows x cols
-    const double* p;
-    int ld, rows, cols;
-    bool tr;
-};
-
-__device__ __forceinline__ double xl_at(const XlMat& X, int r, int c)
-{
-    return (r < X.rows && c < X.cols) ? (X.tr ? X.p[c * X.ld + r] : X.p[r * X.ld + c]) : 0.0;
-}
-
-// Tile (it, jt) of A B', A: I x kd, B' = B + diag I: kd x J; the chain of every element runs over k = 0 ... kd-1.
-template <bool DIAG = false>
-__device__ __forceinline__ d4 xl_tile(const XlMat& A, const XlMat& Bm, int it, int jt, int kd, int g, int c,
-                                      double diag = 0.0)
+// Tile (it, jt) of A B', the chain of every element running over kb k-blocks of four (k = 0 ... 4 kb - 1; what lies
+// beyond the matrices reads as zero, see XlBw).  TA: A is stored transposed (element (i, k) at A[k * lda + i]), else
+// at A[i * lda + k]; TB likewise for element (k, j) of B.  DIAG: B' = B + diag I for k < n (V_xx + mu * eye,
+// ilqr_core.py:210).  The operands of four k-blocks are loaded together, ahead of their MFMAs.
+template <bool TA, bool TB, bool DIAG = false>
+__device__ __forceinline__ d4 xl_tile(const double* A, int lda, const double* Bm, int ldb, int it, int jt, int kb, int g,
+                                      int c, double diag = 0.0, int n = 0)
 {
     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
     const int i = 16 * it + c, j = 16 * jt + c;
-    for (int k0 = 0; k0 < kd; k0 += 4) {
-        const int k = k0 + g;
-        const double a = xl_at(A, i, k);
-        double b = xl_at(Bm, k, j);
-        if (DIAG && k < kd)
-            b = b + (k == j ? diag : 0.0); // V_xx + mu * eye   (ilqr_core.py:210)
+    const double* pa = TA ? A + g * lda + i : A + i * lda + g;
+    const double* pb = TB ? Bm + j * ldb + g : Bm + g * ldb + j;
+    const int sa = TA ? 4 * lda : 4, sb = TB ? 4 : 4 * ldb;
+    int q = 0;
+    for (; q + 4 <= kb; q += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = pa[u * sa];
+            b[u] = pb[u * sb];
+        }
+        if (DIAG) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * (q + u) + g;
+                if (k < n)
+                    b[u] = b[u] + (k == j ? diag : 0.0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            acc = xl_mfma(a[u], b[u], acc);
+        pa += 4 * sa;
+        pb += 4 * sb;
+    }
+    for (; q < kb; ++q) {
+        double a = pa[0], b = pb[0];
+        if (DIAG) {
+            const int k = 4 * q + g;
+            if (k < n)
+                b = b + (k == j ? diag : 0.0);
+        }
         acc = xl_mfma(a, b, acc);
+        pa += sa;
+        pb += sb;
     }
     return acc;
 }
@@ -164,254 +203,385 @@ __device__ __forceinline__ void xl_tile_store(double* O, int ld, int rows, int c
 }
 
 // ---- Cholesky and triangular solves of the free block (m <= 16) ------------------------------------------------
+//
+// boxQP and everything around it in a backward step is the work of wavefront 0 alone, and none of it reads memory
+// inside a chain: lane a < 16 owns variable a and keeps row a of Q_uu and of its Cholesky factor in registers; what a
+// chain needs from another row is a lane read with a constant lane; 16-vectors that every lane needs (the iterate,
+// the search direction) are held replicated.  Variables beyond m do not exist for the reference: they are exact
+// zeros outside every mask, and so are the rows and columns of clamped variables in the factor (the reference
+// compacts the free variables, ilqr_boxQP.py:114-132; fma(a, 0, s) == s keeps the same terms in the same order).
 
-// Lower Cholesky factor of the rows/columns `fm` of H (what the reference factorises after compacting the free
-// variables, ilqr_boxQP.py:114-116: the same chains, the clamped indices skipped), run by one wavefront: lane a owns
-// row a; column by column, the pivot's square root and reciprocal, then every row below it in parallel -- each
-// entry the k-ascending chain t = fma(-L[a][k], L[j][k], t) of LAPACK's dpotf2, scaled by the reciprocal.
-// Reads the lower triangle of H.  False on a non-positive (or NaN) pivot.
-__device__ bool xl_chol(const double* H, double* Lf, double* rd, int m, unsigned fm, int lane)
+// v of `lane` (wave-uniform index) on every lane.  The result is handed on as an ordinary vector register: the
+// compiler would otherwise keep every replicated number in scalar registers, of which there are far too few for
+// the replicated 16-vectors below (they ended up spilled, lane by lane, into vector registers and from there into
+// scratch memory).
+__device__ __forceinline__ double xl_rl(double v, int lane)
 {
-    for (int j = 0; j < m; ++j) {
-        if (!((fm >> j) & 1u))
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    double r = __hiloint2double(hi, lo);
+    asm volatile("" : "+v"(r)); // (volatile: not to be merged with an equal read elsewhere and kept alive in between)
+    return r;
+}
+// a condition that is the same on every lane, as a scalar (keeps the control flow around it wave-uniform)
+__device__ __forceinline__ bool xl_uni(bool c) { return __builtin_amdgcn_readfirstlane(c ? 1 : 0) != 0; }
+
+struct XlFac {
+    double Lr[XM]; // lane a: L[a][j] (0 for j > a and in the rows / columns of clamped variables)
+    double rd[XM]; // 1 / L[j][j], the same on every lane (1 for a clamped j)
+    unsigned fm;   // the free set it belongs to
+};
+
+// Lower Cholesky factor of the rows/columns `fm` of H (Hr: lane a holds row a): column by column the pivot's chain,
+// square root and reciprocal, then every row below it -- each entry the k-ascending chain
+// t = fma(-L[a][k], L[j][k], t) of LAPACK's dpotf2 over the free k, scaled by the reciprocal.  False on a
+// non-positive (or NaN) pivot.
+__device__ __forceinline__ bool xl_chol(const double (&Hr)[XM], unsigned fm, int lane, XlFac& F)
+{
+    const bool fa = lane < XM && ((fm >> lane) & 1u);
+    F.fm = fm;
+#pragma unroll
+    for (int j = 0; j < XM; ++j) {
+        if (!((fm >> j) & 1u)) {
+            F.Lr[j] = 0.0;
+            F.rd[j] = 1.0;
             continue;
-        const bool mine = lane < m && lane >= j && ((fm >> lane) & 1u);
-        double t = 0.0;
-        if (mine) {
-            t = H[lane * LDM + j];
-            for (int k = 0; k < j; ++k)
-                if ((fm >> k) & 1u)
-                    t = fma(-Lf[lane * LDM + k], Lf[j * LDM + k], t);
         }
-        const double s = __shfl(t, j);
-        if (!(s > 0.0))
+        __builtin_amdgcn_sched_barrier(0);
+        double t = Hr[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+            t = fma(-F.Lr[k], xl_rl(F.Lr[k], j), t);
+        const double s = xl_rl(t, j);
+        if (!xl_uni(s > 0.0))
             return false;
         const double d = sqrt(s);
         const double r = 1.0 / d;
-        if (mine)
-            Lf[lane * LDM + j] = (lane == j) ? d : t * r;
-        if (lane == j)
-            rd[j] = r;
-        xl_wave_sync();
+        F.Lr[j] = lane == j ? d : ((fa && lane > j) ? t * r : 0.0);
+        F.rd[j] = r;
     }
     return true;
 }
 
-// (L L^T) x = b in place for the rows/columns `fm` (cho_solve, each substitution multiplying by the reciprocal of
-// the diagonal entry); every lane solves its own right-hand side, the factor is read from LDS.
-__device__ __forceinline__ void xl_chol_solve(const double* Lf, const double* rd, int m, unsigned fm, double (&b)[XM])
+// (L L^T) x = b in place for the rows/columns fm (cho_solve, each substitution multiplying by the reciprocal of
+// the diagonal entry); every lane solves its own right-hand side (all the same one, or one per lane).  Entries of
+// clamped variables must be 0 on entry and are 0 on exit.
+// ones: the factor is the all-ones matrix boxQP starts with (H_ff = np.ones((n, n)), ilqr_boxQP.py:36), fm = all.
+__device__ __forceinline__ void xl_chol_solve(const XlFac& F, unsigned fm, bool ones, double (&b)[XM])
 {
 #pragma unroll
     for (int i = 0; i < XM; ++i) {
-        if (i < m && ((fm >> i) & 1u)) {
-            double s = b[i];
+        __builtin_amdgcn_sched_barrier(0); // (one row's lane reads at a time: hoisted together they fill the registers)
+        double s = b[i];
 #pragma unroll
-            for (int j = 0; j < i; ++j)
-                if ((fm >> j) & 1u)
-                    s = fma(-Lf[i * LDM + j], b[j], s);
-            b[i] = s * rd[i];
+        for (int j = 0; j < i; ++j) {
+            const double l = xl_rl(F.Lr[j], i);
+            s = fma(ones ? -1.0 : -l, b[j], s);
         }
+        b[i] = ((fm >> i) & 1u) ? s * (ones ? 1.0 : F.rd[i]) : 0.0;
     }
 #pragma unroll
     for (int i = XM - 1; i >= 0; --i) {
-        if (i < m && ((fm >> i) & 1u)) {
-            double s = b[i];
+        __builtin_amdgcn_sched_barrier(0);
+        double s = b[i];
 #pragma unroll
-            for (int j = i + 1; j < XM; ++j)
-                if (j < m && ((fm >> j) & 1u))
-                    s = fma(-Lf[j * LDM + i], b[j], s);
-            b[i] = s * rd[i];
+        for (int j = i + 1; j < XM; ++j) {
+            const double l = xl_rl(F.Lr[i], j);
+            s = fma(ones ? -1.0 : -l, b[j], s);
         }
+        b[i] = ((fm >> i) & 1u) ? s * (ones ? 1.0 : F.rd[i]) : 0.0;
     }
 }
 
-// ---- boxQP (ilqr_boxQP.py:9-186) on one wavefront -----------------------------------------------------------
+// ---- wavefront 0 of a backward step: PD test, warm start, boxQP, gains ------------------------------------------
 
-struct XlQpRes {
-    int result;
-    unsigned fm; // free variables at the last classification
-    int n_iter, n_factor, n_backtrack;
-    bool ok; // false: the reference would have raised LinAlgError
+struct XlQpOut {
+    int flag;           // XL_STEP_*
+    int n_iter, n_backtrack;
+    bool clamped;       // a control is clamped at the solution
+    double dJ1, dJ2;    // k.Q_u and 0.5 k.(Q_uu k)
 };
 
-// objective x.g + 0.5 x^T H x of a candidate held in registers (:62, :148): every chain in the reference's order
-__device__ __forceinline__ double xl_value(const XlBw& W, int m, const double (&x)[XM])
+enum { XL_STEP_OK = 0, XL_STEP_NOT_PD = 1, XL_STEP_LINALG = 2 };
+
+// objective x.g + 0.5 x^T H x of a candidate held in registers (ilqr_boxQP.py:62, :148), every chain in the
+// reference's order: (x^T H)_j for two columns j at a time -- a loop that is NOT unrolled (see below) -- then the
+// chain over the columns, for which the candidate is also kept in LDS (xq [16][64], the lane's own column; a
+// register array cannot be indexed by the loop counter).  g = W.Qu and H = W.H are read from LDS (zeros beyond m).
+__device__ __forceinline__ double xl_value(const XlBw& W, double* xq, int lane, const double (&x)[XM])
 {
+#pragma unroll
+    for (int i = 0; i < XM; ++i)
+        xq[i * 64 + lane] = x[i];
     double xg = x[0] * W.Qu[0];
 #pragma unroll
     for (int i = 1; i < XM; ++i)
-        if (i < m)
-            xg = fma(x[i], W.Qu[i], xg);
+        xg = fma(x[i], W.Qu[i], xg);
     double tot = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < XM; j += 2) {
+        const double* h = W.H + j;
+        double a0 = x[0] * h[0], a1 = x[0] * h[1];
 #pragma unroll
-    for (int j = 0; j < XM; ++j) {
-        if (j < m) {
-            double acc = x[0] * W.H[0 * LDM + j];
-#pragma unroll
-            for (int i = 1; i < XM; ++i)
-                if (i < m)
-                    acc = fma(x[i], W.H[i * LDM + j], acc);
-            tot = (j == 0) ? acc * x[0] : fma(acc, x[j], tot);
+        for (int i = 1; i < XM; ++i) {
+            a0 = fma(x[i], h[i * LDM], a0);
+            a1 = fma(x[i], h[i * LDM + 1], a1);
         }
+        const double x0 = xq[j * 64 + lane], x1 = xq[(j + 1) * 64 + lane];
+        tot = (j == 0) ? a0 * x0 : fma(a0, x0, tot);
+        tot = fma(a1, x1, tot);
     }
     return xg + 0.5 * tot;
 }
 
-// In: W.H (Q_uu, finite and positive definite: the caller has factorised it), W.Qu (g), W.lo, W.hi, W.qx (x0).
-// Out: W.qx (x), W.Lf / W.rd (H_ff of the free set; all ones if no factorisation happened, :36), the result.
-// Lane i < m owns variable i for the gradient and the classification; the Armijo loop (:146-156) evaluates 64
-// consecutive trips at a time, one per lane, and takes the first that ends the loop.
-__device__ XlQpRes xl_boxqp(XlBw& W, const XlQP& O, int m, int lane, double* hand)
+// np.all(np.linalg.eigvals(Q_uu) > 0) else break; R_Q_uu = cholesky(Q_uu); k = cho_solve(R_Q_uu, Q_u) (the warm
+// start, positive sign as the reference has it); boxQP(Q_uu, Q_u, lower - u, upper - u, k) (ilqr_boxQP.py:9-186);
+// K[free] = -cho_solve(H_ff, Q_ux[free]); Delta_J   (ilqr_core.py:134-176).
+//
+// ONE loop runs all of it, as a small state machine (warm start -> boxQP passes -> gains), so that the two long
+// unrolled routines -- the factorisation and the triangular solves, ~10 and ~15 KB of instructions -- exist once
+// each.  Written out at each of their five uses, the wavefront's code outgrew the instruction cache and every step
+// fetched it from memory again (~40 cycles per instruction).
+//
+// In: W.H (Q_uu), W.Qu, W.lo[p], W.hi[p], W.Qux.  Out: k_row [m], K_rows [m][n] (global), W.qx (k), W.Kl (K), the
+// optional records, and the return value.  Uses W.T1 as scratch and leaves it zero.
+// Lane a < m owns variable a for the gradient, the classification and the right-hand side; the Armijo loop
+// (:146-156) evaluates 64 consecutive trips at a time, one per lane, and takes the first that ends the loop.
+__device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, int n, int m, int lane,
+                                               double* __restrict__ k_row, double* __restrict__ K_rows,
+                                               int32_t* free_row, int32_t* result_at)
 {
-    const unsigned all = (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
-    XlQpRes R{-1, 0u, 0, 0, 0, true};
-    unsigned cm = 0u;
-    for (int e = lane; e < XM * LDM; e += 64)
-        W.Lf[e] = 1.0;
-    if (lane < XM)
-        W.rd[lane] = 1.0;
-    double lo = 0.0, hi = 0.0, gl = 0.0;
-    if (lane < m) {
-        lo = W.lo[lane];
-        hi = W.hi[lane];
-        gl = W.Qu[lane];
-        W.qx[lane] = xl_clamp(lo, hi, W.qx[lane]);
-    }
-    xl_wave_sync();
-    double value;
-    {
-        double x0r[XM];
+    XlQpOut out{XL_STEP_OK, 0, 0, false, 0.0, 0.0};
+    double Hr[XM]; // lane a < 16: row a of Q_uu
 #pragma unroll
-        for (int i = 0; i < XM; ++i)
-            x0r[i] = i < m ? W.qx[i] : 0.0;
-        value = xl_value(W, m, x0r);
+    for (int j = 0; j < XM; ++j)
+        Hr[j] = lane < XM ? W.H[(lane & (XM - 1)) * LDM + j] : 0.0;
+    {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < XM; ++j)
+            bad = bad || !(fabs(Hr[j]) < __builtin_inf());
+        if (__any(bad)) {
+            out.flag = XL_STEP_LINALG; // eigvals raises LinAlgError on NaN / Inf
+            return out;
+        }
     }
-    double oldvalue = 0.0;
-    for (int iter = 0; iter < O.max_iter; ++iter) {
-        if (iter > 1 && (oldvalue - value) < O.min_rel * fabs(oldvalue) && (oldvalue - value) > 0) {
-            R.result = 4;
-            break;
-        }
-        oldvalue = value;
-        // grad = g + H x (:82); clamped = at a bound with the gradient pointing outwards (:85-88)
-        bool cl = false;
-        if (lane < m) {
-            const double xi = W.qx[lane];
-            double acc = W.H[lane * LDM + 0] * W.qx[0];
-            for (int j = 1; j < m; ++j)
-                acc = fma(W.H[lane * LDM + j], W.qx[j], acc);
-            const double grad = gl + acc;
-            W.grad[lane] = grad;
-            cl = ((xi == lo) && (grad > 0)) || ((xi == hi) && (grad < 0));
-        }
-        const unsigned oldcm = cm;
-        cm = (unsigned)__ballot(cl) & all;
-        const unsigned fm = all & ~cm;
-        R.fm = fm;
-        xl_wave_sync();
-        if (cm == all) {
-            R.result = 6;
-            break;
-        }
-        if (iter == 1 || oldcm != cm) { // :107-116
-            if (!xl_chol(W.H, W.Lf, W.rd, m, fm, lane)) {
-                R.ok = false;
-                return R;
-            }
-            R.n_factor++;
-        }
-        // sla.norm(grad[free]) (:120); dnrm2 of a single element is its magnitude
-        double ss = 0.0, gfirst = 0.0;
-        bool first = true;
-        for (int a = 0; a < m; ++a)
-            if ((fm >> a) & 1u) {
-                const double ga = W.grad[a];
-                if (first) {
-                    ss = ga * ga;
-                    gfirst = ga;
-                    first = false;
-                } else {
-                    ss = fma(ga, ga, ss);
+    const unsigned all = (1u << m) - 1u;
+    const int la = lane < XM ? lane : 0;
+    const double* lov = W.lo[p];
+    const double* hiv = W.hi[p];
+    const double lo = lov[la], hi = hiv[la], gl = W.Qu[la]; // (zeros beyond m)
+    double* xq = W.T1;
+
+    enum { WARM, PASS, GAINS };
+    int mode = WARM;
+    XlFac F;
+    F.fm = ~0u;
+    double x[XM], srch[XM];
+    unsigned cm = 0u, fm = 0u; // clamped set (none before the first classification, :28) and free set of boxQP
+    bool factored = false;     // false: H_ff is still the all-ones matrix of :36
+    int result = -1, iter = 0;
+    double value = 0.0, oldvalue = 0.0, grad = 0.0;
+    for (;;) {
+        bool want_chol = false;
+        unsigned fq = all;
+        if (mode == WARM) {
+            want_chol = true;
+        } else if (mode == PASS) {
+            if (iter >= O.max_iter || result != -1) {
+                mode = GAINS;
+            } else if (iter > 1 && xl_uni((oldvalue - value) < O.min_rel * fabs(oldvalue) && (oldvalue - value) > 0)) {
+                result = 4;
+                mode = GAINS;
+            } else {
+                oldvalue = value;
+                // grad = g + H x (:82); clamped = at a bound with the gradient pointing outwards (:85-88)
+                double acc = Hr[0] * x[0];
+#pragma unroll
+                for (int j = 1; j < XM; ++j)
+                    acc = fma(Hr[j], x[j], acc);
+                grad = gl + acc;
+                double xa = 0.0; // the lane's own variable
+#pragma unroll
+                for (int a = 0; a < XM; ++a)
+                    xa = lane == a ? x[a] : xa;
+                const bool cl = lane < m && (((xa == lo) && (grad > 0)) || ((xa == hi) && (grad < 0)));
+                const unsigned oldcm = cm;
+                cm = (unsigned)__ballot(cl) & all;
+                fm = all & ~cm;
+                if (lane < XM)
+                    W.grad[lane] = lane < m ? grad : 0.0;
+                xl_wave_sync();
+                if (cm == all) {
+                    result = 6;
+                    mode = GAINS;
+                } else if (iter == 1 || oldcm != cm) { // :107-116
+                    factored = true;
+                    want_chol = fm != F.fm; // (else the same inputs would give the same bits)
+                    fq = fm;
                 }
             }
-        const double gnorm = __popc(fm) == 1 ? fabs(gfirst) : sqrt(ss);
-        if (gnorm < O.min_grad) {
-            R.result = 5;
-            break;
         }
-        R.n_iter++;
-        // search[free] = -cho_solve(H_ff, g[free] + H_fc x[clamped]) - x[free]   (:126-132)
-        double b[XM];
-#pragma unroll
-        for (int a = 0; a < XM; ++a) {
-            b[a] = 0.0;
-            if (a < m && ((fm >> a) & 1u)) {
-                double acc = 0.0;
-                bool fst = true;
-                for (int q = 0; q < m; ++q)
-                    if ((cm >> q) & 1u) {
-                        acc = fst ? W.H[a * LDM + q] * W.qx[q] : fma(W.H[a * LDM + q], W.qx[q], acc);
-                        fst = false;
-                    }
-                b[a] = W.Qu[a] + acc;
+        if (want_chol) {
+            if (!xl_chol(Hr, fq, lane, F)) {
+                out.flag = mode == WARM ? XL_STEP_NOT_PD : XL_STEP_LINALG;
+                break;
             }
         }
-        xl_chol_solve(W.Lf, W.rd, m, fm, b);
+        if (mode == PASS) {
+            // sla.norm(grad[free]) (:120); dnrm2 of a single element is its magnitude
+            double ss = 0.0; // (fma(g, g, 0) is the product g * g: the chain starts at the first free variable)
+#pragma unroll
+            for (int a = 0; a < XM; ++a) {
+                const double ga = ((fm >> a) & 1u) ? W.grad[a] : 0.0;
+                ss = fma(ga, ga, ss);
+            }
+            const double gnorm = __popc(fm) == 1 ? fabs(W.grad[__ffs((int)fm) - 1]) : sqrt(ss);
+            if (xl_uni(gnorm < O.min_grad)) {
+                result = 5;
+                mode = GAINS;
+            } else {
+                out.n_iter++;
+            }
+        }
+        // the right-hand side: Q_u (warm start); g[free] + H_fc x[clamped] (:126-131; lane a forms entry a, the chain
+        // over the clamped variables starts at the first of them: fma(h, x, 0) is the product); a column of Q_ux
+        double b[XM];
+        unsigned sm = all;
+        bool ones = false;
+        if (mode == WARM) {
+#pragma unroll
+            for (int a = 0; a < XM; ++a)
+                b[a] = W.Qu[a];
+        } else if (mode == PASS) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < XM; ++q)
+                acc = fma(Hr[q], ((cm >> q) & 1u) ? x[q] : 0.0, acc);
+            const double bv = (lane < XM && ((fm >> lane) & 1u)) ? gl + acc : 0.0;
+#pragma unroll
+            for (int a = 0; a < XM; ++a)
+                b[a] = xl_rl(bv, a);
+            sm = fm;
+            ones = !factored;
+        } else {
+#pragma unroll
+            for (int a = 0; a < XM; ++a)
+                b[a] = ((fm >> a) & 1u) ? W.Qux[a * LDN + lane] : 0.0;
+            sm = fm;
+            ones = !factored;
+        }
+        if (sm != 0u)
+            xl_chol_solve(F, sm, ones, b);
+        if (mode == WARM) {
+#pragma unroll
+            for (int a = 0; a < XM; ++a)
+                x[a] = xl_clamp(lov[a], hiv[a], b[a]); // x = clamp(x0)   (:42)
+            value = xl_value(W, xq, lane, x);
+            mode = PASS;
+            continue;
+        }
+        if (mode == GAINS) {
+            // K[free, :] = -cho_solve(H_ff, Q_ux[free, :]), zero rows for the clamped controls (:157-160)
+            if (lane < n) {
+#pragma unroll
+                for (int a = 0; a < XM; ++a)
+                    if (a < m) {
+                        const double v = ((fm >> a) & 1u) ? b[a] * -1 : 0.0;
+                        W.Kl[a * LDN + lane] = v;
+                        K_rows[(int64_t)a * n + lane] = v;
+                    }
+            }
+            break;
+        }
+        // search[free] = -cho_solve(H_ff, .) - x[free]   (:132)
 #pragma unroll
         for (int a = 0; a < XM; ++a)
-            if (a < m)
-                W.srch[a] = ((fm >> a) & 1u) ? b[a] * -1 - W.qx[a] : 0.0; // (every lane writes the same number)
-        xl_wave_sync();
-        // Armijo loop (:141-156): trip t tries step_dec^t (formed by repeated multiplication, as the loop does);
-        // it ends at the first trip whose test fails or, from the second trip on, whose step is below min_step.
+            srch[a] = ((fm >> a) & 1u) ? b[a] * -1 - x[a] : 0.0;
+        // Armijo loop (:141-156): trip t tries step_dec^t (formed by repeated multiplication, as the loop does: the
+        // table holds those numbers, beyond it they are formed here); it ends at the first trip whose test fails
+        // or, from the second trip on, whose step is below min_step.
         double base = 1.0;
         int t0 = 0;
         for (;;) {
-            double st = base, mine = base;
-            for (int q = 0; q < 64; ++q) {
-                if (q == lane)
-                    mine = st;
-                st = st * O.step_dec;
+            double mine;
+            if (t0 + 64 <= XTAB) {
+                mine = W.steps[t0 + lane];
+                if (t0 + 64 == XTAB)
+                    base = W.steps[XTAB - 1] * O.step_dec;
+            } else {
+                double st = base;
+                mine = base;
+                for (int q = 0; q < 64; ++q) {
+                    if (q == lane)
+                        mine = st;
+                    st = st * O.step_dec;
+                }
+                base = st;
             }
             double xc[XM];
 #pragma unroll
             for (int a = 0; a < XM; ++a)
-                xc[a] = a < m ? xl_clamp(W.lo[a], W.hi[a], W.qx[a] + mine * W.srch[a]) : 0.0;
-            double sd = (xc[0] - W.qx[0]) * W.grad[0];
+                xc[a] = xl_clamp(lov[a], hiv[a], x[a] + mine * srch[a]);
+            double sd = (xc[0] - x[0]) * W.grad[0];
 #pragma unroll
             for (int a = 1; a < XM; ++a)
-                if (a < m)
-                    sd = sd + (xc[a] - W.qx[a]) * W.grad[a];
-            const double vc = xl_value(W, m, xc);
+                sd = sd + (xc[a] - x[a]) * W.grad[a];
+            const double vc = xl_value(W, xq, lane, xc);
             const bool cont = (vc - oldvalue) / (sd + 1e-10) < O.armijo;
             const bool exh = (t0 + lane >= 1) && (mine < O.min_step);
             const unsigned long long bal = __ballot(!cont || exh);
             if (bal != 0ull) {
                 const int l = __ffsll((long long)bal) - 1;
-                xl_wave_sync(); // every lane has read the old x
-                if (lane == l) {
 #pragma unroll
-                    for (int a = 0; a < XM; ++a)
-                        if (a < m)
-                            W.qx[a] = xc[a];
-                    hand[0] = vc;
-                    hand[1] = exh ? 2.0 : 0.0;
-                }
-                xl_wave_sync();
-                value = hand[0];
-                if (hand[1] != 0.0)
-                    R.result = 2;
-                R.n_backtrack += t0 + l;
-                xl_wave_sync();
+                for (int a = 0; a < XM; ++a)
+                    x[a] = xl_rl(xc[a], l);
+                value = xl_rl(vc, l);
+                if ((__ballot(exh) >> l) & 1ull)
+                    result = 2;
+                out.n_backtrack += t0 + l;
                 break;
             }
             t0 += 64;
-            base = st;
         }
-        if (R.result != -1)
-            break;
+        xl_wave_sync(); // (W.grad is rewritten by the next pass)
+        ++iter;
     }
-    return R;
+#pragma unroll
+    for (int a = 0; a < XM; ++a)
+        xq[a * 64 + lane] = 0.0; // (T1 is zero outside its n x m)
+    if (out.flag != XL_STEP_OK)
+        return out;
+    out.clamped = __popc(fm) < m;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < XM; ++a)
+            W.qx[a] = x[a];
+        if (result_at)
+            *result_at = result;
+    }
+    xl_wave_sync();
+    if (lane < m) {
+        k_row[lane] = W.qx[lane];
+        if (free_row)
+            free_row[lane] = (int32_t)((fm >> lane) & 1u);
+    }
+    // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)   (:175-176)
+    double qa = Hr[0] * x[0];
+#pragma unroll
+    for (int q = 1; q < XM; ++q)
+        qa = fma(Hr[q], x[q], qa);
+    double d1 = x[0] * W.Qu[0];
+#pragma unroll
+    for (int q = 1; q < XM; ++q)
+        d1 = fma(x[q], W.Qu[q], d1);
+    double d2 = x[0] * xl_rl(qa, 0);
+#pragma unroll
+    for (int q = 1; q < XM; ++q)
+        d2 = fma(x[q], xl_rl(qa, q), d2);
+    out.dJ1 = d1;
+    out.dJ2 = d2 * 0.5;
+    return out;
 }
 
 // ---- backward sweep ---------------------------------------------------------------------------------------
@@ -421,158 +591,193 @@ struct XlBwOut {
     int stopped_at, qp_iter, qp_backtrack, n_clamped, rc;
 };
 
-enum { XL_STEP_OK = 0, XL_STEP_NOT_PD = 1, XL_STEP_LINALG = 2 };
+// What a backward step needs that does not depend on the recursion -- x_j, the cost gradients, c phi'(W x_j), and
+// f_x = I + dt (A + diag(c phi') W) -- formed by wavefronts 1..3 (hw = 0..2) one step ahead, while wavefront 0 runs
+// the boxQP of step j + 1.  Each wavefront forms c phi'(W x_j) for itself (no hand-over between them) and writes
+// the column blocks jt = hw, hw + 3 of f_x: the blocks whose tiles of Q_xx it has just finished, so nobody still
+// reads what it overwrites.  Wavefront 3 also forms l_x, wavefront 2 the control part (l_u and the box).
+template <bool PATH>
+__device__ __forceinline__ void xl_stage_step(const XlP& P, XlBw& W, const double* __restrict__ xs,
+                                              const double* __restrict__ us, int j, int hw, int lane)
+{
+    const int n = __builtin_amdgcn_readfirstlane(P.n), m = __builtin_amdgcn_readfirstlane(P.m);
+    const int NT = (n + 15) >> 4, p = j & 1, g = lane >> 4, c = lane & 15;
+    const double* xg = PATH ? P.xg + (int64_t)j * n : P.xg;
+    const double* ug = PATH ? P.ug + (int64_t)j * m : P.ug;
+    if (lane < n) {
+        const double xv = xs[(int64_t)j * n + lane];
+        W.xw[hw][lane] = xv;
+        if (hw == 2)
+            W.xd[p][lane] = xv - xg[lane];
+    }
+    if (hw == 1 && lane < m) {
+        const double uv = us[(int64_t)j * m + lane];
+        W.ud[p][lane] = uv - ug[lane];
+        W.lo[p][lane] = P.lower[lane] - uv;
+        W.hi[p][lane] = P.upper[lane] - uv;
+    }
+    xl_wave_sync();
+    if (lane < n) { // phi'(z) = (1 + z^2)^(-3/2), z = W x
+        const double* wr = P.W + lane * n;
+        double z = wr[0] * W.xw[hw][0];
+        for (int q = 1; q < n; ++q)
+            z = fma(wr[q], W.xw[hw][q], z);
+        const double s = 1.0 + z * z;
+        W.gi[hw][lane] = P.sig_c * (1.0 / (s * sqrt(s)));
+    }
+    if (hw == 2 && lane < n) { // l_x = x_diff^T (Q + Q^T)   (ilqr_cost.py:555-569)
+        double acc = W.xd[p][0] * (P.Q[0 * n + lane] + P.Q[lane * n + 0]);
+        for (int a = 1; a < n; ++a)
+            acc = fma(W.xd[p][a], P.Q[a * n + lane] + P.Q[lane * n + a], acc);
+        W.lx[p][lane] = acc;
+    }
+    if (hw == 1 && lane < m) { // l_u = u_diff^T (R + R^T)   (:571-587)
+        double acc = W.ud[p][0] * (P.R[0 * m + lane] + P.R[lane * m + 0]);
+        for (int a = 1; a < m; ++a)
+            acc = fma(W.ud[p][a], P.R[a * m + lane] + P.R[lane * m + a], acc);
+        W.lu[p][lane] = acc;
+    }
+    xl_wave_sync();
+    for (int jt = hw; jt < NT; jt += 3) {
+        const int b = 16 * jt + c;
+        if (b < n)
+            for (int a = g; a < n; a += 4)
+                W.fx[a * LDN + b] = (a == b ? 1.0 : 0.0) + P.dt * (P.A[a * n + b] + W.gi[hw][a] * P.W[a * n + b]);
+    }
+}
 
 // _backward_pass + _compute_Q_terms (ilqr_core.py:109-228) of one problem, run by the whole workgroup.
 // k [T*m], K [T*m*n] are fully written (zeros where the sweep did not reach).
+//
+// A step: (1) all four wavefronts: M1 = f_x^T V_xx, M2 = f_u^T (V_xx + mu I), Q_x, Q_u; (2) Q_ux = M2 f_x and
+// Q_uu = l_uu + M2 f_u; (3) wavefront 0: PD test, warm start, boxQP, gains -- the one serial part -- while
+// wavefronts 1..3 form Q_xx = l_xx + M1 f_x (which boxQP does not need; each keeps the tiles of its column blocks in
+// registers) and then stage the next step (xl_stage_step); (4) T1 = K^T Q_uu; (5) the value update, each tile by
+// the wavefront that holds its Q_xx; (6) symmetrisation.
 template <bool PATH>
-__device__ void xl_backward(const XlP& P, const XlQP& QO, XlMem& S, const double* __restrict__ xs,
+__device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem& S, const double* __restrict__ xs,
                             const double* __restrict__ us, double mu, double* __restrict__ k, double* __restrict__ K,
                             XlBwOut& o, int32_t* qp_result, int32_t* free_mask)
 {
     XlBw& W = S.bw;
-    const int n = P.n, m = P.m, T = P.T, NT = (n + 15) >> 4;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    // (the sizes as scalars: every loop below is the same for all lanes)
+    const int n = __builtin_amdgcn_readfirstlane(P.n), m = __builtin_amdgcn_readfirstlane(P.m),
+              T = __builtin_amdgcn_readfirstlane(P.T);
+    const int NT = (n + 15) >> 4, KN = (n + 3) >> 2, KM = (m + 3) >> 2;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lane0 = lane;
     if (qp_result)
         for (int i = tid; i < T; i += 256)
             qp_result[i] = -100; // step not reached
     if (free_mask)
         for (int i = tid; i < T * m; i += 256)
             free_mask[i] = 0;
+    __syncthreads(); // (whoever used this memory before has finished)
+    {
+        double* z = reinterpret_cast<double*>(&W);
+        for (int e = tid; e < (int)(sizeof(XlBw) / sizeof(double)); e += 256)
+            z[e] = 0.0;
+    }
+    __syncthreads();
+    // what stays the same for the whole sweep: f_u = dt B, the Armijo step table
+    for (int e = tid; e < n * m; e += 256)
+        W.fu[(e / m) * LDM + e % m] = P.dt * P.B[e];
+    if (tid == 255) {
+        double st = 1.0;
+        for (int t = 0; t < XTAB; ++t) {
+            W.steps[t] = st;
+            st = st * QO.step_dec;
+        }
+    }
     // V_x = l_x(x_N), V_xx = l_xx(x_N)   (:127-128)
     if (tid < n)
-        W.xd[tid] = xs[(int64_t)T * n + tid] - (PATH ? P.xg[(int64_t)T * n + tid] : P.xg[tid]);
+        W.Qx[tid] = xs[(int64_t)T * n + tid] - (PATH ? P.xg[(int64_t)T * n + tid] : P.xg[tid]); // (x_diff, for a moment)
     __syncthreads();
     if (tid < n) {
         const int j = tid;
-        double acc = W.xd[0] * (P.Qt[0 * n + j] + P.Qt[j * n + 0]);
+        double acc = W.Qx[0] * (P.Qt[0 * n + j] + P.Qt[j * n + 0]);
         for (int a = 1; a < n; ++a)
-            acc = fma(W.xd[a], P.Qt[a * n + j] + P.Qt[j * n + a], acc);
+            acc = fma(W.Qx[a], P.Qt[a * n + j] + P.Qt[j * n + a], acc);
         W.Vx[j] = acc;
     }
     for (int e = tid; e < n * n; e += 256) {
         const int a = e / n, b = e % n;
         W.Vxx[a * LDN + b] = P.Qt[a * n + b] + P.Qt[b * n + a];
     }
+    if (wave >= 1)
+        xl_stage_step<PATH>(P, W, xs, us, T - 1, wave - 1, lane);
     double dJ1 = 0.0, dJ2 = 0.0; // (wave 0's; handed to the workgroup at the end)
     int qp_iter = 0, qp_bt = 0, n_cl = 0;
     o.stopped_at = -1;
     o.rc = 0;
     __syncthreads();
 
+    const XlP& P0 = P;
+    const double* const xs0 = xs;
+    const double* const us0 = us;
+    double* const k0 = k;
+    double* const K0 = K;
     for (int i = T - 1; i >= 0; --i) {
-        const double* xg = PATH ? P.xg + (int64_t)i * n : P.xg;
-        const double* ug = PATH ? P.ug + (int64_t)i * m : P.ug;
-        // -- operands of the step
-        if (tid < n) {
-            const double xv = xs[(int64_t)i * n + tid];
-            W.x[tid] = xv;
-            W.xd[tid] = xv - xg[tid];
-        } else if (tid >= 64 && tid < 64 + m) {
-            const int j = tid - 64;
-            const double uv = us[(int64_t)i * m + j];
-            W.u[j] = uv;
-            W.ud[j] = uv - ug[j];
-            W.lo[j] = P.lower[j] - uv;
-            W.hi[j] = P.upper[j] - uv;
-        }
-        if (tid == 0)
-            S.res_i[0] = XL_STEP_OK;
-        __syncthreads();
-        // -- chains per row: phi'(W x), l_x, l_u
-        if (wave == 0) {
-            if (lane < n) {
-                double z = P.W[lane * n + 0] * W.x[0];
-                for (int j = 1; j < n; ++j)
-                    z = fma(P.W[lane * n + j], W.x[j], z);
-                const double s = 1.0 + z * z;
-                W.gi[lane] = P.sig_c * (1.0 / (s * sqrt(s)));
+        const int p = i & 1;
+        // The model and the arrays as this step sees them: the pointers are made opaque once per step, so that the
+        // addresses (and loop-invariant loads) the compiler derives from them are formed where they are used instead
+        // of being kept -- hundreds of registers' worth -- across the steps.
+        XlP P = P0;
+        const double* xs = xs0;
+        const double* us = us0;
+        double* k = k0;
+        double* K = K0;
+        asm volatile("" : "+s"(P.A), "+s"(P.W), "+s"(P.Q), "+s"(P.R), "+s"(P.lower), "+s"(P.upper), "+s"(P.xg), "+s"(P.ug));
+        asm volatile("" : "+s"(xs), "+s"(us), "+s"(k), "+s"(K));
+        // (the same for what is derived from the lane index, the LDS addresses of every tile: afresh in every phase)
+        int lane, g, c;
+#define XL_FRESH_LANE()                 \
+    lane = lane0;                       \
+    asm volatile("" : "+v"(lane));      \
+    g = lane >> 4;                      \
+    c = lane & 15
+        XL_FRESH_LANE();
+        XP_T(c0);
+        // -- (1) M1 = f_x^T V_xx, M2 = f_u^T (V_xx + mu I); Q_x, Q_u   (:200-212)
+        for (int q = wave; q < NT * NT + NT; q += 4) {
+            if (q < NT * NT) {
+                const int it = q / NT, jt = q - it * NT;
+                xl_tile_store(W.M1, LDN, n, n, it, jt, xl_tile<true, false>(W.fx, LDN, W.Vxx, LDN, it, jt, KN, g, c), g, c);
+            } else {
+                const int jt = q - NT * NT;
+                xl_tile_store(W.M2, LDN, m, n, 0, jt,
+                              xl_tile<true, false, true>(W.fu, LDM, W.Vxx, LDN, 0, jt, KN, g, c, mu, n), g, c);
             }
-        } else if (wave == 1) {
+        }
+        if (wave == 3) {
             if (lane < n) {
-                const int j = lane;
-                double acc = W.xd[0] * (P.Q[0 * n + j] + P.Q[j * n + 0]);
+                double acc = W.fx[0 * LDN + lane] * W.Vx[0];
                 for (int a = 1; a < n; ++a)
-                    acc = fma(W.xd[a], P.Q[a * n + j] + P.Q[j * n + a], acc);
-                W.lx[j] = acc;
+                    acc = fma(W.fx[a * LDN + lane], W.Vx[a], acc);
+                W.Qx[lane] = W.lx[p][lane] + acc;
             }
         } else if (wave == 2) {
             if (lane < m) {
-                const int j = lane;
-                double acc = W.ud[0] * (P.R[0 * m + j] + P.R[j * m + 0]);
-                for (int a = 1; a < m; ++a)
-                    acc = fma(W.ud[a], P.R[a * m + j] + P.R[j * m + a], acc);
-                W.lu[j] = acc;
+                double acc = W.fu[0 * LDM + lane] * W.Vx[0];
+                for (int a = 1; a < n; ++a)
+                    acc = fma(W.fu[a * LDM + lane], W.Vx[a], acc);
+                W.Qu[lane] = W.lu[p][lane] + acc;
             }
         }
         __syncthreads();
-        // -- f_x = I + dt (A + c diag(phi'(W x)) W), f_u = dt B
-        for (int e = tid; e < n * n; e += 256) {
-            const int a = e / n, b = e % n;
-            W.fx[a * LDN + b] = (a == b ? 1.0 : 0.0) + P.dt * (P.A[e] + W.gi[a] * P.W[e]);
-        }
-        for (int e = tid; e < n * m; e += 256)
-            W.fu[(e / m) * LDM + e % m] = P.dt * P.B[e];
-        __syncthreads();
-        // -- M1 = f_x^T V_xx, M2 = f_u^T (V_xx + mu I); Q_x, Q_u   (:200-212)
-        {
-            const XlMat fxT{W.fx, LDN, n, n, true}, fuT{W.fu, LDM, m, n, true}, Vm{W.Vxx, LDN, n, n, false};
-            for (int q = wave; q < NT * NT + NT; q += 4) {
-                if (q < NT * NT) {
-                    const int it = q / NT, jt = q % NT;
-                    xl_tile_store(W.M1, LDN, n, n, it, jt, xl_tile(fxT, Vm, it, jt, n, g, c), g, c);
-                } else {
-                    const int jt = q - NT * NT;
-                    xl_tile_store(W.M2, LDN, m, n, 0, jt, xl_tile<true>(fuT, Vm, 0, jt, n, g, c, mu), g, c);
-                }
-            }
-            if (wave == 3) {
-                if (lane < n) {
-                    double acc = W.fx[0 * LDN + lane] * W.Vx[0];
-                    for (int a = 1; a < n; ++a)
-                        acc = fma(W.fx[a * LDN + lane], W.Vx[a], acc);
-                    W.Qx[lane] = W.lx[lane] + acc;
-                }
-            } else if (wave == 2) {
-                if (lane < m) {
-                    double acc = W.fu[0 * LDM + lane] * W.Vx[0];
-                    for (int a = 1; a < n; ++a)
-                        acc = fma(W.fu[a * LDM + lane], W.Vx[a], acc);
-                    W.Qu[lane] = W.lu[lane] + acc;
-                }
-            }
-        }
-        __syncthreads();
-        // -- Q_xx = l_xx + M1 f_x (kept in registers by the wavefront that owns the tile), Q_ux = M2 f_x,
-        //    Q_uu = l_uu + M2 f_u
-        d4 qxx[4];
-        {
-            const XlMat M1m{W.M1, LDN, n, n, false}, M2m{W.M2, LDN, m, n, false}, fxm{W.fx, LDN, n, n, false},
-                fum{W.fu, LDM, n, m, false};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int q = wave + 4 * s;
-                qxx[s] = d4{0.0, 0.0, 0.0, 0.0};
-                if (q < NT * NT) {
-                    const int it = q / NT, jt = q % NT;
-                    const d4 acc = xl_tile(M1m, fxm, it, jt, n, g, c);
-                    const int b = 16 * jt + c;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int a = 16 * it + 4 * r + g;
-                        qxx[s][r] = (a < n && b < n) ? (P.Q[a * n + b] + P.Q[b * n + a]) + acc[r] : 0.0;
-                    }
-                }
-            }
-            for (int jt = wave; jt < NT; jt += 4) {
-                d4 acc = xl_tile(M2m, fxm, 0, jt, n, g, c);
+        XP_T(c1);
+        XP_ADD(0, c0, c1);
+        XL_FRESH_LANE();
+        // -- (2) Q_ux = M2 f_x, Q_uu = l_uu + M2 f_u
+        for (int q = wave; q < NT + 1; q += 4) {
+            if (q < NT) {
+                d4 acc = xl_tile<false, false>(W.M2, LDN, W.fx, LDN, 0, q, KN, g, c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc[r] = 0.0 + acc[r]; // l_ux is identically zero
-                xl_tile_store(W.Qux, LDN, m, n, 0, jt, acc, g, c);
-            }
-            if (wave == (NT < 4 ? NT : 3)) { // (the wavefront with the fewest tiles above)
-                d4 acc = xl_tile(M2m, fum, 0, 0, n, g, c);
+                xl_tile_store(W.Qux, LDN, m, n, 0, q, acc, g, c);
+            } else {
+                d4 acc = xl_tile<false, false>(W.M2, LDN, W.fu, LDM, 0, 0, KN, g, c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int a = 4 * r + g;
@@ -583,82 +788,55 @@ __device__ void xl_backward(const XlP& P, const XlQP& QO, XlMem& S, const double
             }
         }
         __syncthreads();
-        // -- wave 0: PD test, warm start, boxQP, gains, Delta_J   (:134-176)
+        XP_T(c2);
+        XP_ADD(1, c1, c2);
+        XL_FRESH_LANE();
+        // -- (3) wave 0: PD test, warm start, boxQP, gains, Delta_J (:134-176); waves 1..3: Q_xx, then the next step
+        d4 qxx[8]; // tiles (it, jt = hw + 3 bs) at [4 bs + it]
         if (wave == 0) {
-            bool bad = false;
-            for (int e = lane; e < m * m; e += 64)
-                bad = bad || !(fabs(W.H[(e / m) * LDM + e % m]) < __builtin_inf());
-            const unsigned all = (1u << m) - 1u;
-            int flag = XL_STEP_OK;
-            if (__any(bad)) {
-                flag = XL_STEP_LINALG; // eigvals raises LinAlgError on NaN / Inf
-            } else if (!xl_chol(W.H, W.Lf, W.rd, m, all, lane)) {
-                flag = XL_STEP_NOT_PD;
-            } else {
-                // k = cho_solve(R_Q_uu, Q_u): the warm start of boxQP (positive sign, as the reference has it)
-                double b[XM];
-#pragma unroll
-                for (int a = 0; a < XM; ++a)
-                    b[a] = a < m ? W.Qu[a] : 0.0;
-                xl_chol_solve(W.Lf, W.rd, m, all, b);
-#pragma unroll
-                for (int a = 0; a < XM; ++a)
-                    if (a < m)
-                        W.qx[a] = b[a];
-                xl_wave_sync();
-                const XlQpRes R = xl_boxqp(W, QO, m, lane, S.res_d);
-                if (!R.ok) {
-                    flag = XL_STEP_LINALG;
-                } else {
-                    qp_iter += R.n_iter;
-                    qp_bt += R.n_backtrack;
-                    if (__popc(R.fm) < m)
-                        ++n_cl;
-                    if (lane < m) {
-                        k[(int64_t)i * m + lane] = W.qx[lane];
-                        if (free_mask)
-                            free_mask[(int64_t)i * m + lane] = (int32_t)((R.fm >> lane) & 1u);
-                    }
-                    if (lane == 0 && qp_result)
-                        qp_result[i] = R.result;
-                    // K[free, :] = -cho_solve(H_ff, Q_ux[free, :]), zero rows for the clamped controls (:157-160)
-                    if (lane < n) {
-                        double col[XM];
-#pragma unroll
-                        for (int a = 0; a < XM; ++a)
-                            col[a] = (a < m && ((R.fm >> a) & 1u)) ? W.Qux[a * LDN + lane] : 0.0;
-                        if (R.fm != 0u)
-                            xl_chol_solve(W.Lf, W.rd, m, R.fm, col);
-#pragma unroll
-                        for (int a = 0; a < XM; ++a)
-                            if (a < m) {
-                                const double v = ((R.fm >> a) & 1u) ? col[a] * -1 : 0.0;
-                                W.Kl[a * LDN + lane] = v;
-                                K[((int64_t)i * m + a) * n + lane] = v;
-                            }
-                    }
-                    // Delta_J1 += k.Q_u ; Delta_J2 += 0.5 k.(Q_uu k)   (:175-176)
-                    if (lane < m) {
-                        double acc = W.H[lane * LDM + 0] * W.qx[0];
-                        for (int q = 1; q < m; ++q)
-                            acc = fma(W.H[lane * LDM + q], W.qx[q], acc);
-                        W.qa[lane] = acc;
-                    }
-                    xl_wave_sync();
-                    double d1 = W.qx[0] * W.Qu[0];
-                    for (int q = 1; q < m; ++q)
-                        d1 = fma(W.qx[q], W.Qu[q], d1);
-                    double d2 = W.qx[0] * W.qa[0];
-                    for (int q = 1; q < m; ++q)
-                        d2 = fma(W.qx[q], W.qa[q], d2);
-                    dJ1 = dJ1 + d1;
-                    dJ2 = dJ2 + d2 * 0.5;
-                }
+            const XlQpOut q = xl_qp_phase(W, p, QO, n, m, lane, k + (int64_t)i * m, K + (int64_t)i * m * n,
+                                          free_mask ? free_mask + (int64_t)i * m : nullptr,
+                                          qp_result ? qp_result + i : nullptr);
+            if (q.flag == XL_STEP_OK) {
+                qp_iter += q.n_iter;
+                qp_bt += q.n_backtrack;
+                if (q.clamped)
+                    ++n_cl;
+                dJ1 = dJ1 + q.dJ1;
+                dJ2 = dJ2 + q.dJ2;
             }
             if (lane == 0)
-                S.res_i[0] = flag;
+                S.res_i[0] = q.flag;
+            XP_T(c2c);
+            XP_ADD(12, c2, c2c);
+        } else {
+            const int hw = wave - 1;
+#pragma unroll
+            for (int bs = 0; bs < 2; ++bs)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int jt = hw + 3 * bs;
+                    d4 v = d4{0.0, 0.0, 0.0, 0.0};
+                    if (jt < NT && it < NT) {
+                        const d4 acc = xl_tile<false, false>(W.M1, LDN, W.fx, LDN, it, jt, KN, g, c);
+                        const int b = 16 * jt + c;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int a = 16 * it + 4 * r + g;
+                            v[r] = (a < n && b < n) ? (P.Q[a * n + b] + P.Q[b * n + a]) + acc[r] : 0.0;
+                        }
+                    }
+                    qxx[4 * bs + it] = v;
+                }
+            xl_wave_sync(); // (this wavefront's reads of its f_x blocks are done)
+            XL_FRESH_LANE();
+            if (i > 0)
+                xl_stage_step<PATH>(P, W, xs, us, i - 1, hw, lane);
         }
         __syncthreads();
+        XP_T(c3);
+        XP_ADD(2, c2, c3);
+        XL_FRESH_LANE();
         const int flag = S.res_i[0];
         if (flag == XL_STEP_LINALG) {
             o.rc = -1;
@@ -672,33 +850,16 @@ __device__ void xl_backward(const XlP& P, const XlQP& QO, XlMem& S, const double
                 K[e] = 0.0;
             break;
         }
-        // -- T1 = K^T Q_uu
-        {
-            const XlMat KT{W.Kl, LDN, n, m, true}, Hm{W.H, LDM, m, m, false};
-            for (int it = wave; it < NT; it += 4)
-                xl_tile_store(W.T1, LDM, n, m, it, 0, xl_tile(KT, Hm, it, 0, m, g, c), g, c);
-        }
+        // -- (4) T1 = K^T Q_uu
+        for (int it = wave; it < NT; it += 4)
+            xl_tile_store(W.T1, LDM, n, m, it, 0, xl_tile<true, false>(W.Kl, LDN, W.H, LDM, it, 0, KM, g, c), g, c);
         __syncthreads();
-        // -- V_xx = Q_xx + (K^T Q_uu) K + K^T Q_ux + Q_ux^T K (unsymmetrised, into M1's place); V_x   (:164-167)
-        {
-            const XlMat T1m{W.T1, LDM, n, m, false}, Km{W.Kl, LDN, m, n, false}, KT{W.Kl, LDN, n, m, true},
-                Quxm{W.Qux, LDN, m, n, false}, QuxT{W.Qux, LDN, n, m, true};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int q = wave + 4 * s;
-                if (q < NT * NT) {
-                    const int it = q / NT, jt = q % NT;
-                    const d4 t1 = xl_tile(T1m, Km, it, jt, m, g, c);
-                    const d4 t2 = xl_tile(KT, Quxm, it, jt, m, g, c);
-                    const d4 t3 = xl_tile(QuxT, Km, it, jt, m, g, c);
-                    d4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = ((qxx[s][r] + t1[r]) + t2[r]) + t3[r];
-                    xl_tile_store(W.M1, LDN, n, n, it, jt, v, g, c);
-                }
-            }
-            if (wave == 0 && lane < n) {
+        XP_T(c4);
+        XP_ADD(3, c3, c4);
+        XL_FRESH_LANE();
+        // -- (5) V_xx = Q_xx + (K^T Q_uu) K + K^T Q_ux + Q_ux^T K (unsymmetrised, into M1's place); V_x   (:164-167)
+        if (wave == 0) {
+            if (lane < n) {
                 const int a = lane;
                 double t1 = W.T1[a * LDM + 0] * W.qx[0];
                 double t2 = W.Kl[0 * LDN + a] * W.Qu[0];
@@ -710,14 +871,37 @@ __device__ void xl_backward(const XlP& P, const XlQP& QO, XlMem& S, const double
                 }
                 W.Vx[a] = ((W.Qx[a] + t1) + t2) + t3;
             }
+        } else {
+            const int hw = wave - 1;
+#pragma unroll
+            for (int bs = 0; bs < 2; ++bs)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int jt = hw + 3 * bs;
+                    if (jt < NT && it < NT) {
+                        const d4 t1 = xl_tile<false, false>(W.T1, LDM, W.Kl, LDN, it, jt, KM, g, c);
+                        const d4 t2 = xl_tile<true, false>(W.Kl, LDN, W.Qux, LDN, it, jt, KM, g, c);
+                        const d4 t3 = xl_tile<true, false>(W.Qux, LDN, W.Kl, LDN, it, jt, KM, g, c);
+                        d4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[r] = ((qxx[4 * bs + it][r] + t1[r]) + t2[r]) + t3[r];
+                        xl_tile_store(W.M1, LDN, n, n, it, jt, v, g, c);
+                    }
+                }
         }
         __syncthreads();
-        // -- V_xx = 0.5 (V_xx + V_xx^T)   (:168)
-        for (int e = tid; e < n * n; e += 256) {
-            const int a = e / n, b = e % n;
-            W.Vxx[a * LDN + b] = 0.5 * (W.M1[a * LDN + b] + W.M1[b * LDN + a]);
-        }
+        XP_T(c5);
+        XP_ADD(4, c4, c5);
+        XL_FRESH_LANE();
+        // -- (6) V_xx = 0.5 (V_xx + V_xx^T)   (:168)
+        for (int a = wave; a < n; a += 4)
+            if (lane < n)
+                W.Vxx[a * LDN + lane] = 0.5 * (W.M1[a * LDN + lane] + W.M1[lane * LDN + a]);
         __syncthreads();
+        XP_T(c6);
+        XP_ADD(5, c5, c6);
+#undef XL_FRESH_LANE
     }
     // wave 0's sums to everybody
     __syncthreads();
@@ -1123,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_xl_solve(XlP P, XlSolveOpts O, int64_t 
         if (threadIdx.x == 0)
             S.next = atomicAdd(queue, 1);
         __syncthreads();
-        const int64_t b = S.next;
+        const int64_t b = __builtin_amdgcn_readfirstlane(S.next); // (a scalar: every address below is the same on all lanes)
         __syncthreads();
         if (b >= B)
             break;
@@ -1341,5 +1525,16 @@ int ilqr_xl_solve_batched(const ilqr_large_model* model, const ilqr_opts* opts, 
                            us_init, delta, k, K, xs, us, ws, queue, J, mu, iters, status, tr);
     return xrc(hipGetLastError());
 }
+
+#ifdef ILQR_XL_PROF
+int ilqr_xl_debug_prof(unsigned long long* host16, int reset)
+{
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return xrc(hipMemcpyToSymbol(HIP_SYMBOL(g_xl_prof), z, sizeof(z)));
+    }
+    return xrc(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_xl_prof), 16 * sizeof(unsigned long long)));
+}
+#endif
 
 } // extern "C"
