@@ -84,6 +84,7 @@ struct XlBw {
     double T1[XN * LDM];  // K^T Q_uu
     double Qux[XM * LDN], Kl[XM * LDN];
     double H[XM * LDM];  // Q_uu
+    double Lf[XM * XM];  // the Cholesky factor the triangular solves read (zeros in the rows / columns of clamped variables)
     double steps[XTAB];
     // operands of a step, written one step ahead by wavefronts 1..3 while wavefront 0 runs boxQP: two sets, used in
     // turn by the parity of the step
@@ -263,34 +264,78 @@ __device__ __forceinline__ bool xl_chol(const double (&Hr)[XM], unsigned fm, int
     return true;
 }
 
+// The factor as the triangular solves read it: row a by lane a into LDS (every entry of a solve's chain is then one
+// broadcast load, against six instructions for a lane read).
+__device__ __forceinline__ void xl_fac_store(const XlFac& F, double* Lm, int lane)
+{
+    if (lane < XM) {
+#pragma unroll
+        for (int j = 0; j < XM; ++j)
+            Lm[lane * XM + j] = F.Lr[j];
+    }
+    xl_wave_sync();
+}
+
 // (L L^T) x = b in place for the rows/columns fm (cho_solve, each substitution multiplying by the reciprocal of
 // the diagonal entry); every lane solves its own right-hand side (all the same one, or one per lane).  Entries of
-// clamped variables must be 0 on entry and are 0 on exit.
-// ones: the factor is the all-ones matrix boxQP starts with (H_ff = np.ones((n, n)), ilqr_boxQP.py:36), fm = all.
-__device__ __forceinline__ void xl_chol_solve(const XlFac& F, unsigned fm, bool ones, double (&b)[XM])
+// clamped variables must be 0 on entry and are 0 on exit.  Lm: the factor in LDS (xl_fac_store); a row's entries
+// are loaded while the chain of the row before runs.
+// ONES: the factor is the all-ones matrix boxQP starts with (H_ff = np.ones((n, n)), ilqr_boxQP.py:36), fm = all.
+template <bool ONES>
+__device__ __forceinline__ void xl_chol_solve_t(const XlFac& F, const double* Lm, unsigned fm, double (&b)[XM])
 {
+    double nxt[XM];
+#pragma unroll
+    for (int j = 0; j < XM; ++j)
+        nxt[j] = 0.0;
+    if (!ONES)
+        nxt[0] = Lm[1 * XM + 0];
 #pragma unroll
     for (int i = 0; i < XM; ++i) {
-        __builtin_amdgcn_sched_barrier(0); // (one row's lane reads at a time: hoisted together they fill the registers)
+        __builtin_amdgcn_sched_barrier(0);
+        double cur[XM];
+#pragma unroll
+        for (int j = 0; j < XM; ++j)
+            cur[j] = nxt[j];
+        if (!ONES && i + 1 < XM) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j)
+                nxt[j] = Lm[(i + 1) * XM + j];
+        }
         double s = b[i];
 #pragma unroll
-        for (int j = 0; j < i; ++j) {
-            const double l = xl_rl(F.Lr[j], i);
-            s = fma(ones ? -1.0 : -l, b[j], s);
-        }
-        b[i] = ((fm >> i) & 1u) ? s * (ones ? 1.0 : F.rd[i]) : 0.0;
+        for (int j = 0; j < i; ++j)
+            s = ONES ? fma(-1.0, b[j], s) : fma(-cur[j], b[j], s);
+        b[i] = ((fm >> i) & 1u) ? (ONES ? s * 1.0 : s * F.rd[i]) : 0.0;
+    }
+    if (!ONES) { // column XM - 2 below the diagonal
+        nxt[XM - 1] = Lm[(XM - 1) * XM + XM - 2];
     }
 #pragma unroll
     for (int i = XM - 1; i >= 0; --i) {
         __builtin_amdgcn_sched_barrier(0);
+        double cur[XM];
+#pragma unroll
+        for (int j = 0; j < XM; ++j)
+            cur[j] = nxt[j];
+        if (!ONES && i - 1 >= 0 && i - 1 < XM - 2) { // column i - 1: L[j][i - 1], j > i - 1 (column XM - 2 is in hand)
+#pragma unroll
+            for (int j = i; j < XM; ++j)
+                nxt[j] = Lm[j * XM + (i - 1)];
+        }
         double s = b[i];
 #pragma unroll
-        for (int j = i + 1; j < XM; ++j) {
-            const double l = xl_rl(F.Lr[i], j);
-            s = fma(ones ? -1.0 : -l, b[j], s);
-        }
-        b[i] = ((fm >> i) & 1u) ? s * (ones ? 1.0 : F.rd[i]) : 0.0;
+        for (int j = i + 1; j < XM; ++j)
+            s = ONES ? fma(-1.0, b[j], s) : fma(-cur[j], b[j], s);
+        b[i] = ((fm >> i) & 1u) ? (ONES ? s * 1.0 : s * F.rd[i]) : 0.0;
     }
+}
+__device__ __forceinline__ void xl_chol_solve(const XlFac& F, const double* Lm, unsigned fm, bool ones, double (&b)[XM])
+{
+    if (ones)
+        xl_chol_solve_t<true>(F, Lm, fm, b);
+    else
+        xl_chol_solve_t<false>(F, Lm, fm, b);
 }
 
 // ---- wavefront 0 of a backward step: PD test, warm start, boxQP, gains ------------------------------------------
@@ -427,6 +472,7 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
                 out.flag = mode == WARM ? XL_STEP_NOT_PD : XL_STEP_LINALG;
                 break;
             }
+            xl_fac_store(F, W.Lf, lane);
         }
         if (mode == PASS) {
             // sla.norm(grad[free]) (:120); dnrm2 of a single element is its magnitude
@@ -472,7 +518,7 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
             ones = !factored;
         }
         if (sm != 0u)
-            xl_chol_solve(F, sm, ones, b);
+            xl_chol_solve(F, W.Lf, sm, ones, b);
         if (mode == WARM) {
 #pragma unroll
             for (int a = 0; a < XM; ++a)
