@@ -713,6 +713,7 @@ struct WaveMem { // per problem (= per wave)
     double Qux[LM][LN + 1];
     double K[LM][LN + 1];
     double Vn[LN][LN + 1];
+    double zb[LA][LN + 1], lxb[LA][LN + 1]; // W x and l_x of 16 consecutive steps (backward sweep)
     double J[LA];
 };
 
@@ -836,6 +837,56 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
     for (int i = T - 1; i >= 0; --i) {
         long long t_a = prof ? clock64() : 0;
         { // ---- matrix part 1: f_x, then what the boxQP needs (Q_u, Q_ux, Q_uu)
+        // W x (for the Jacobian) and l_x of a step depend on the trajectory only, not on the recursion: they are
+        // formed for 16 steps at a time -- the 16 states as the columns of a 32 x 16 matrix, one product each
+        // instead of sixteen matrix-vector products that use a sixteenth of every MFMA -- and kept in LDS.
+        // Column c of the block that starts at step i is step i - c; each column's chains are those of its own
+        // matrix-vector product, term for term.
+        const int cb = (T - 1 - i) & (LA - 1);
+        if (cb == 0) {
+            d4 X16[2][1], XD16[2][1];
+            const int st = i - L.c > 0 ? i - L.c : 0; // (columns beyond step 0 repeat it; nobody reads them)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + L.g + 4 * r;
+                    const double xvv = xs[(size_t)st * LN + row];
+                    X16[rt][0][r] = xvv;
+                    XD16[rt][0][r] = xvv - (PATH ? P.xg[(size_t)st * LN + row] : xg[rt][0][r]);
+                }
+#ifndef ILQR_LARGE_USER_MODEL
+            {
+                d4 WT[2][2], Z16[2][1];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        WT[rt][ct] = load_nt(&M.W[0][0], LN + 1, LN, LN, rt, ct, L);
+                mm_tn<2, 2, 1>(WT, X16, Z16);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        S.zb[L.c][16 * rt + L.g + 4 * r] = Z16[rt][0][r];
+            }
+#endif
+            {
+                d4 QQ[2][2], LX16[2][1];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        QQ[rt][ct] = load_n(&M.QQ[0][0], LN + 1, LN, LN, rt, ct, L);
+                mm_tn<2, 2, 1>(QQ, XD16, LX16); // l_x[j] = sum_a x_diff[a] (Q + Q^T)[a][j]   (ilqr_cost.py:555-569)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        S.lxb[L.c][16 * rt + L.g + 4 * r] = LX16[rt][0][r];
+            }
+            wave_sync();
+        }
         d4 xv[2][1], uv[1][1];
         xv[0][0] = load_v(xs + (size_t)i * LN, LN, 0, L);
         xv[1][0] = load_v(xs + (size_t)i * LN, LN, 1, L);
@@ -869,13 +920,9 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         // z = W x, g_i = c phi'(z_i), f_x = I + dt (A + diag(g) W)
         d4 fx[2][2];
         {
-            d4 WT[2][2], z[2][1];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    WT[rt][ct] = load_nt(&M.W[0][0], LN + 1, LN, LN, rt, ct, L);
-            mm_tn<2, 2, 1>(WT, xv, z);
+            d4 z[2][1];
+            z[0][0] = load_v(S.zb[cb], LN, 0, L);
+            z[1][0] = load_v(S.zb[cb], LN, 1, L);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 d4 gi;
@@ -1027,11 +1074,12 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         // ---- back to the matrix part: reload what was parked, then Q_x and Q_xx
         d4 Qx[2][1], Qxx[2][2];
         {
-            d4 fx[2][2], QQ[2][2], xd[2][1], lx[2][1];
+            d4 fx[2][2], QQ[2][2], lx[2][1];
+            const int cb = (T - 1 - i) & (LA - 1);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 Vx[rt][0] = load_v(S.vx, LN, rt, L);
-                xd[rt][0] = load_v(xs + (size_t)i * LN, LN, rt, L) - xg[rt][0];
+                lx[rt][0] = load_v(S.lxb[cb], LN, rt, L); // (formed with the block of 16 steps, above)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     fx[rt][ct] = load_n(&S.Vn[0][0], LN + 1, LN, LN, rt, ct, L);
@@ -1040,8 +1088,7 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
                 }
             }
             wave_sync(); // S.Vn is reused below
-            // l_x (ilqr_cost.py:555-569) ; Q_x = l_x + f_x^T V_x          (:206)
-            mm_tn<2, 2, 1>(QQ, xd, lx);
+            // Q_x = l_x + f_x^T V_x          (:206)
             mm_tn<2, 2, 1>(fx, Vx, Qx);
             Qx[0][0] = lx[0][0] + Qx[0][0];
             Qx[1][0] = lx[1][0] + Qx[1][0];
