@@ -714,6 +714,7 @@ struct WaveMem { // per problem (= per wave)
     double K[LM][LN + 1];
     double Vn[LN][LN + 1];
     double zb[LA][LN + 1], lxb[LA][LN + 1]; // W x and l_x of 16 consecutive steps (backward sweep)
+    double fxvx[LN];                        // f_x^T V_x of the step in hand
     double J[LA];
 };
 
@@ -959,7 +960,9 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
             Qu[0][0] = lu[0][0] + Qu[0][0];
         }
         // reg = V_xx + mu I ; M2^T = reg^T f_u ; Q_ux = M2 f_x ; Q_uu = l_uu + M2 f_u   (:210-212)
-        d4 Qux[1][2], Quu[1][1];
+        // Q_ux is formed transposed, as f_x^T [M2^T | V_x]: the same products term for term (a b = b a), and the
+        // ninth column of the same 16 MFMAs is f_x^T V_x, the product Q_x needs (:206)
+        d4 QuxT[2][1], Quu[1][1];
         {
             d4 reg[2][2], M2T[2][1];
 #pragma unroll
@@ -972,11 +975,15 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
                         reg[rt][ct][r] = Vxx[rt][ct][r] + mu * id;
                     }
             mm_tn<2, 2, 1>(reg, fu, M2T);
-            mm_tn<2, 1, 2>(M2T, fx, Qux);
             mm_tn<2, 1, 1>(M2T, fu, Quu);
-            Qux[0][0] = 0.0 + Qux[0][0];
-            Qux[0][1] = 0.0 + Qux[0][1];
             Quu[0][0] = RR[0][0] + Quu[0][0];
+            d4 Y[2][1];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Y[rt][0][r] = L.c == LM ? Vx[rt][0][r] : M2T[rt][0][r];
+            mm_tn<2, 2, 1>(fx, Y, QuxT);
         }
         // ---- hand Q_uu, Q_u, Q_ux and the bounds to the scalar part through LDS, and park f_x, V_xx,
         // V_x there as well: the boxQP below needs the registers, and what it does not need
@@ -994,8 +1001,16 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
         store_v(S.g, LM, 0, Qu[0][0], L);
         store_v(S.lo, LM, 0, load_v(M.lower, LM, 0, L) - uv[0][0], L);
         store_v(S.hi, LM, 0, load_v(M.upper, LM, 0, L) - uv[0][0], L);
-        store_n(&S.Qux[0][0], LN + 1, LM, LN, 0, 0, Qux[0][0], L);
-        store_n(&S.Qux[0][0], LN + 1, LM, LN, 0, 1, Qux[0][1], L);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * rt + L.g + 4 * r;
+                if (L.c < LM)
+                    S.Qux[L.c][j] = 0.0 + QuxT[rt][0][r]; // (l_ux is identically zero)
+                else if (L.c == LM)
+                    S.fxvx[j] = QuxT[rt][0][r];
+            }
         wave_sync();
         }
         long long t_b = prof ? clock64() : 0;
@@ -1088,10 +1103,9 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
                 }
             }
             wave_sync(); // S.Vn is reused below
-            // Q_x = l_x + f_x^T V_x          (:206)
-            mm_tn<2, 2, 1>(fx, Vx, Qx);
-            Qx[0][0] = lx[0][0] + Qx[0][0];
-            Qx[1][0] = lx[1][0] + Qx[1][0];
+            // Q_x = l_x + f_x^T V_x          (:206; the product came with Q_ux)
+            Qx[0][0] = lx[0][0] + load_v(S.fxvx, LN, 0, L);
+            Qx[1][0] = lx[1][0] + load_v(S.fxvx, LN, 1, L);
             // M1^T = V_xx^T f_x ; Q_xx = l_xx + M1 f_x                    (:208)
             d4 M1T[2][2];
             mm_tn<2, 2, 2>(Vxx, fx, M1T);

@@ -15,7 +15,9 @@ FLOP_BW_STEP = 4 * 32 ** 3 + 10 * 8 * 32 ** 2 + 6 * 8 ** 2 * 32 + 8 ** 3 / 3.0
 # one rollout step for one step size: A x, W x (2 n^2 each), B u, K dx (2 n m each), cost 2 n^2 + 2 m^2
 FLOP_FW_STEP = 3 * 2 * 32 ** 2 + 2 * 2 * 32 * 8 + 2 * 8 ** 2
 # MFMA instructions actually issued (16 x 16 x 4, 2048 flop each) per backward step / per 16-wide rollout step
-MFMA_BW_STEP, MFMA_FW_STEP = 208, 76
+# (162 = 208 less the matrix-vector products W x and l_x, formed for 16 steps at a time, and f_x^T V_x, which rides as
+# a ninth column of the Q_ux product)
+MFMA_BW_STEP, MFMA_FW_STEP = 162, 76
 
 
 def main():
