@@ -1191,7 +1191,8 @@ __device__ void large_backward(const LargeP& P, const LQPOpts& QO, const BlockMe
 // (column c of every matrix belongs to alpha[c]); with ROLL the controls are us themselves
 // (_dynamics_rollout, :69-83).  J of column c ends up in S.J[c].  The trajectory of column
 // `store_col` (if >= 0) is written to xs_new / us_new.
-template <bool ROLL, bool PATH>
+// COST = false: states and controls only (the cost of the stored column is then formed by large_traj_cost).
+template <bool ROLL, bool PATH, bool COST = true>
 __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, const double* us, const double* k,
                               const double* K, const double* x0, double alpha_c, int store_col, double* xs_new,
                               double* us_new)
@@ -1273,7 +1274,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
             }
         }
         // l(x, u) = x_diff^T Q x_diff / 2 + u_diff^T R u_diff / 2   (ilqr_cost.py:532-553)
-        {
+        if (COST) {
             d4 xd[2][1], ud[1][1], ax[2][1], au[1][1], sx[1][1], su[1][1];
             if (PATH) {
                 xg[0] = load_v(P.xg + (size_t)t * LN, LN, 0, L);
@@ -1352,7 +1353,7 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
             for (int r = 0; r < 4; ++r)
                 xs_new[(size_t)T * LN + 16 * rt + L.g + 4 * r] = Xh[rt][0][r];
     }
-    {
+    if (COST) {
         d4 xd[2][1], ax[2][1], sx[1][1];
         if (PATH) {
             xg[0] = load_v(P.xg + (size_t)T * LN, LN, 0, L);
@@ -1370,6 +1371,83 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
             }
     }
     wave_sync();
+}
+
+// _trajectory_cost (ilqr_core.py:230-239) of a stored trajectory: the stage costs of 16 time steps at a time, the
+// 16 steps as the columns of the same products a rollout forms per step for its 16 step sizes (so each l_t has the
+// bits the rollout would give it), then J = J + l_t in the order of t, and the terminal cost.  The same number on
+// every lane.  The line search uses it for the first step size, which is accepted in > 90 % of the iterations: the
+// rollout then carries no cost products (28 of its 76 MFMAs per step), and the cost costs 28 MFMAs per 16 steps.
+template <bool PATH>
+__device__ double large_traj_cost(const LargeP& P, WaveMem& S, const double* xs, const double* us)
+{
+    const LaneId L = lane_id();
+    const int T = P.T;
+    d4 Qn[2][2], Rn[1][1];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+            Qn[rt][ct] = load_n(P.Q, LN, LN, LN, rt, ct, L);
+    Rn[0][0] = load_n(P.R, LM, LM, LM, 0, 0, L);
+    const d4 ug = load_v(P.ug, LM, 0, L);
+    d4 xg[2];
+    xg[0] = load_v(P.xg, LN, 0, L);
+    xg[1] = load_v(P.xg, LN, 1, L);
+    const bool diag_lane[4] = {L.g == L.c, L.g + 4 == L.c, L.g + 8 == L.c, L.g + 12 == L.c};
+    double J = 0.0;
+    for (int t0 = 0; t0 < T; t0 += LA) {
+        const int st = t0 + L.c < T ? t0 + L.c : T - 1; // (columns beyond the last step repeat it; they are not added)
+        d4 xd[2][1], ud[1][1], ax[2][1], au[1][1], sx[1][1], su[1][1];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rt + L.g + 4 * r;
+                xd[rt][0][r] = xs[(size_t)st * LN + row] - (PATH ? P.xg[(size_t)st * LN + row] : xg[rt][r]);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = L.g + 4 * r;
+            ud[0][0][r] = row < LM ? us[(size_t)st * LM + row] - (PATH ? P.ug[(size_t)st * LM + row] : ug[r]) : 0.0;
+        }
+        mm_tn<2, 2, 1>(Qn, xd, ax);
+        mm_tn<2, 1, 1>(ax, xd, sx);
+        mm_tn<1, 1, 1, 2>(Rn, ud, au);
+        mm_tn<1, 1, 1, 2>(au, ud, su);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (diag_lane[r])
+                S.J[L.c] = PATH ? sx[0][0][r] + su[0][0][r] : sx[0][0][r] * 0.5 + su[0][0][r] * 0.5;
+        wave_sync();
+        const int nc = T - t0 < LA ? T - t0 : LA;
+        for (int c = 0; c < nc; ++c)
+            J = J + S.J[c];
+        wave_sync();
+    }
+    {
+        d4 Qtn[2][2], xd[2][1], ax[2][1], sx[1][1];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                Qtn[rt][ct] = load_n(P.Qt, LN, LN, LN, rt, ct, L);
+        if (PATH) {
+            xg[0] = load_v(P.xg + (size_t)T * LN, LN, 0, L);
+            xg[1] = load_v(P.xg + (size_t)T * LN, LN, 1, L);
+        }
+        xd[0][0] = load_v(xs + (size_t)T * LN, LN, 0, L) - xg[0];
+        xd[1][0] = load_v(xs + (size_t)T * LN, LN, 1, L) - xg[1];
+        mm_tn<2, 2, 1>(Qtn, xd, ax);
+        mm_tn<2, 1, 1>(ax, xd, sx);
+        if (diag_lane[0] && L.c == 0)
+            S.J[0] = sx[0][0][0];
+        wave_sync();
+        const double sT = S.J[0];
+        J = J + (PATH ? sT : sT * 0.5);
+        wave_sync();
+    }
+    return J;
 }
 
 // ------------------------------------------------------------------ kernels
@@ -1510,6 +1588,25 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
         double Jnew = 0.0;
         bool ended = false;
         int nxt = cur ^ 1;
+        if (O.n_alpha > 0) {
+            // the first step size, accepted in > 90 % of the iterations: its rollout without the cost products, its
+            // cost from the stored trajectory (large_traj_cost: the same bits); only if it is turned down do the
+            // candidates get rolled out with their costs, below (the scan then starts again at the first step size)
+            const double a = L.c < O.n_alpha ? O.alphas[L.c] : 0.0;
+            large_forward<false, PATH, false>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], a, 0, xsb[nxt],
+                                              usb[nxt]);
+            wave_sync();
+            Jnew = large_traj_cost<PATH>(P, S, xsb[nxt], usb[nxt]);
+            const double alpha = O.alphas[0];
+            const double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
+            if (expected <= 0.0) {
+                ended = true; // reject the whole iteration
+            } else if ((J - Jnew) / expected > O.scale) {
+                actual = J - Jnew;
+                accepted = 1;
+                ended = true;
+            }
+        }
         {
             for (int pass = 0; pass * LA < O.n_alpha && !ended; ++pass) {
                 int jj = pass * LA + L.c;
