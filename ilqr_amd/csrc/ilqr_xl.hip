@@ -40,6 +40,15 @@ __device__ __forceinline__ d4 xl_mfma(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// All of a group of loaded values in registers at this point: the compiler, short of registers in these kernels, would
+// otherwise issue a load, wait for it, use it, and only then issue the next (one LDS latency per term of a chain).
+#define XL_PIN4(a) asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]))
+#define XL_PIN16(a)                                                                                                 \
+    asm volatile(""                                                                                                  \
+                 : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]), "+v"((a)[5]), "+v"((a)[6]),  \
+                   "+v"((a)[7]), "+v"((a)[8]), "+v"((a)[9]), "+v"((a)[10]), "+v"((a)[11]), "+v"((a)[12]),              \
+                   "+v"((a)[13]), "+v"((a)[14]), "+v"((a)[15]))
+
 struct XlP { // kernel arguments: the model, all device pointers, arrays dense ([n*n], [n*m], ...)
     const double *A, *B, *W, *Q, *R, *Qt, *xg, *ug, *lower, *upper;
     double dt, sig_c;
@@ -164,6 +173,8 @@ __device__ __forceinline__ d4 xl_tile(const double* A, int lda, const double* Bm
             a[u] = pa[u * sa];
             b[u] = pb[u * sb];
         }
+        XL_PIN4(a);
+        XL_PIN4(b);
         if (DIAG) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -235,24 +246,33 @@ struct XlFac {
 
 // Lower Cholesky factor of the rows/columns `fm` of H (Hr: lane a holds row a): column by column the pivot's chain,
 // square root and reciprocal, then every row below it -- each entry the k-ascending chain
-// t = fma(-L[a][k], L[j][k], t) of LAPACK's dpotf2 over the free k, scaled by the reciprocal.  False on a
-// non-positive (or NaN) pivot.
-__device__ __forceinline__ bool xl_chol(const double (&Hr)[XM], unsigned fm, int lane, XlFac& F)
+// t = fma(-L[a][k], L[j][k], t) of LAPACK's dpotf2 over the free k, scaled by the reciprocal.  Lane a keeps its row
+// in registers and writes every finished entry to Lm (LDS, [16][16]), from where the pivot row of the next column is
+// read back with broadcast loads (all at once, ahead of the chain) and where the triangular solves find the factor.
+// False on a non-positive (or NaN) pivot.
+__device__ __forceinline__ bool xl_chol(const double (&Hr)[XM], unsigned fm, int lane, XlFac& F, double* Lm)
 {
     const bool fa = lane < XM && ((fm >> lane) & 1u);
+    const int la = lane & (XM - 1);
     F.fm = fm;
 #pragma unroll
     for (int j = 0; j < XM; ++j) {
         if (!((fm >> j) & 1u)) {
             F.Lr[j] = 0.0;
             F.rd[j] = 1.0;
+            if (lane < XM)
+                Lm[la * XM + j] = 0.0;
             continue;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        double lj[XM]; // row j of the factor, columns < j
+#pragma unroll
+        for (int k = 0; k < XM; ++k)
+            lj[k] = k < j ? Lm[j * XM + k] : 0.0;
+        XL_PIN16(lj);
         double t = Hr[j];
 #pragma unroll
         for (int k = 0; k < j; ++k)
-            t = fma(-F.Lr[k], xl_rl(F.Lr[k], j), t);
+            t = fma(-F.Lr[k], lj[k], t);
         const double s = xl_rl(t, j);
         if (!xl_uni(s > 0.0))
             return false;
@@ -260,26 +280,17 @@ __device__ __forceinline__ bool xl_chol(const double (&Hr)[XM], unsigned fm, int
         const double r = 1.0 / d;
         F.Lr[j] = lane == j ? d : ((fa && lane > j) ? t * r : 0.0);
         F.rd[j] = r;
+        if (lane < XM)
+            Lm[la * XM + j] = F.Lr[j];
+        xl_wave_sync();
     }
     return true;
 }
 
-// The factor as the triangular solves read it: row a by lane a into LDS (every entry of a solve's chain is then one
-// broadcast load, against six instructions for a lane read).
-__device__ __forceinline__ void xl_fac_store(const XlFac& F, double* Lm, int lane)
-{
-    if (lane < XM) {
-#pragma unroll
-        for (int j = 0; j < XM; ++j)
-            Lm[lane * XM + j] = F.Lr[j];
-    }
-    xl_wave_sync();
-}
-
 // (L L^T) x = b in place for the rows/columns fm (cho_solve, each substitution multiplying by the reciprocal of
 // the diagonal entry); every lane solves its own right-hand side (all the same one, or one per lane).  Entries of
-// clamped variables must be 0 on entry and are 0 on exit.  Lm: the factor in LDS (xl_fac_store); a row's entries
-// are loaded while the chain of the row before runs.
+// clamped variables must be 0 on entry and are 0 on exit.  Lm: the factor in LDS; a row's entries
+// are loaded while the chain of the row before runs.  (xl_chol leaves the factor there.)
 // ONES: the factor is the all-ones matrix boxQP starts with (H_ff = np.ones((n, n)), ilqr_boxQP.py:36), fm = all.
 template <bool ONES>
 __device__ __forceinline__ void xl_chol_solve_t(const XlFac& F, const double* Lm, unsigned fm, double (&b)[XM])
@@ -366,11 +377,19 @@ __device__ __forceinline__ double xl_value(const XlBw& W, double* xq, int lane, 
 #pragma unroll 1
     for (int j = 0; j < XM; j += 2) {
         const double* h = W.H + j;
-        double a0 = x[0] * h[0], a1 = x[0] * h[1];
+        double h0[XM], h1[XM];
+#pragma unroll
+        for (int i = 0; i < XM; ++i) {
+            h0[i] = h[i * LDM];
+            h1[i] = h[i * LDM + 1];
+        }
+        XL_PIN16(h0);
+        XL_PIN16(h1);
+        double a0 = x[0] * h0[0], a1 = x[0] * h1[0];
 #pragma unroll
         for (int i = 1; i < XM; ++i) {
-            a0 = fma(x[i], h[i * LDM], a0);
-            a1 = fma(x[i], h[i * LDM + 1], a1);
+            a0 = fma(x[i], h0[i], a0);
+            a1 = fma(x[i], h1[i], a1);
         }
         const double x0 = xq[j * 64 + lane], x1 = xq[(j + 1) * 64 + lane];
         tot = (j == 0) ? a0 * x0 : fma(a0, x0, tot);
@@ -468,11 +487,13 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
             }
         }
         if (want_chol) {
-            if (!xl_chol(Hr, fq, lane, F)) {
+            XP_T(f0);
+            if (!xl_chol(Hr, fq, lane, F, W.Lf)) {
                 out.flag = mode == WARM ? XL_STEP_NOT_PD : XL_STEP_LINALG;
                 break;
             }
-            xl_fac_store(F, W.Lf, lane);
+            XP_T(f1);
+            XP_ADD(6, f0, f1);
         }
         if (mode == PASS) {
             // sla.norm(grad[free]) (:120); dnrm2 of a single element is its magnitude
@@ -517,8 +538,11 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
             sm = fm;
             ones = !factored;
         }
+        XP_T(s0);
         if (sm != 0u)
             xl_chol_solve(F, W.Lf, sm, ones, b);
+        XP_T(s1);
+        XP_ADD(7, s0, s1);
         if (mode == WARM) {
 #pragma unroll
             for (int a = 0; a < XM; ++a)
@@ -547,6 +571,7 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
         // Armijo loop (:141-156): trip t tries step_dec^t (formed by repeated multiplication, as the loop does: the
         // table holds those numbers, beyond it they are formed here); it ends at the first trip whose test fails
         // or, from the second trip on, whose step is below min_step.
+        XP_T(a0);
         double base = 1.0;
         int t0 = 0;
         for (;;) {
@@ -590,6 +615,8 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
             }
             t0 += 64;
         }
+        XP_T(a1);
+        XP_ADD(8, a0, a1);
         xl_wave_sync(); // (W.grad is rewritten by the next pass)
         ++iter;
     }
@@ -795,20 +822,30 @@ __device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem&
                               xl_tile<true, false, true>(W.fu, LDM, W.Vxx, LDN, 0, jt, KN, g, c, mu, n), g, c);
             }
         }
-        if (wave == 3) {
-            if (lane < n) {
-                double acc = W.fx[0 * LDN + lane] * W.Vx[0];
-                for (int a = 1; a < n; ++a)
-                    acc = fma(W.fx[a * LDN + lane], W.Vx[a], acc);
+        // Q_x = l_x + f_x^T V_x, Q_u = l_u + f_u^T V_x (:206-207): lane = entry, the chain over the states 16 terms at a
+        // time (operands beyond n are zeros: fma(0, 0, s) == s)
+        if (wave == 3 || wave == 2) {
+            const double* col = wave == 3 ? W.fx + lane : W.fu + (lane & (XM - 1));
+            const int ld = wave == 3 ? LDN : LDM;
+            double acc = 0.0;
+            for (int a0 = 0; a0 < 16 * NT; a0 += 16) {
+                double fv[16], vv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    fv[q] = col[(a0 + q) * ld];
+                    vv[q] = W.Vx[a0 + q];
+                }
+                XL_PIN16(fv);
+                XL_PIN16(vv);
+                acc = a0 == 0 ? fv[0] * vv[0] : fma(fv[0], vv[0], acc);
+#pragma unroll
+                for (int q = 1; q < 16; ++q)
+                    acc = fma(fv[q], vv[q], acc);
+            }
+            if (wave == 3 && lane < n)
                 W.Qx[lane] = W.lx[p][lane] + acc;
-            }
-        } else if (wave == 2) {
-            if (lane < m) {
-                double acc = W.fu[0 * LDM + lane] * W.Vx[0];
-                for (int a = 1; a < n; ++a)
-                    acc = fma(W.fu[a * LDM + lane], W.Vx[a], acc);
+            if (wave == 2 && lane < m)
                 W.Qu[lane] = W.lu[p][lane] + acc;
-            }
         }
         __syncthreads();
         XP_T(c1);

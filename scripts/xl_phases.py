@@ -26,7 +26,7 @@ O = _hip.Opts(max_iter=12)
 L = _hip._large_lib(M)
 buf = (C.c_ulonglong * 16)()
 names = {0: "(1) M1, M2, Q_x, Q_u", 1: "(2) Q_ux, Q_uu", 2: "(3) until every wavefront is through: boxQP (wave 0) / Q_xx + staging",
-         12: "    of which wave 0 (PD test, warm start, boxQP, gains)", 3: "(4) T1", 4: "(5) value update", 5: "(6) symmetrise"}
+         12: "    of which wave 0 (PD test, warm start, boxQP, gains)", 6: "      factorisations", 7: "      triangular solves", 8: "      Armijo rounds", 3: "(4) T1", 4: "(5) value update", 5: "(6) symmetrise"}
 
 
 def report(tag, steps):
