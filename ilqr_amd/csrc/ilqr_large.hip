@@ -709,7 +709,7 @@ struct WaveMem { // per problem (= per wave)
     double H[LM * LM], g[LM], lo[LM], hi[LM], x[LM]; // Q_uu, Q_u, bounds, boxQP solution
     double Lf[LM][LM];                               // boxQP factor
     double vx[LN];                                   // parked V_x
-    double P1[LN][LN + 1];                           // parking space for a 32 x 32 tile set
+    alignas(16) double P1[LN][LN + 1];               // parking space for a 32 x 32 tile set
     double Qux[LM][LN + 1];
     double K[LM][LN + 1];
     double Vn[LN][LN + 1];
@@ -1373,6 +1373,135 @@ __device__ void large_forward(const LargeP& P, WaveMem& S, const double* xs, con
     wave_sync();
 }
 
+#ifndef ILQR_LARGE_USER_MODEL
+// _forward_pass (ilqr_core.py:85-107) for ONE step size, without costs: what the line search runs first (its first
+// step size is accepted in > 90 % of the iterations).  A rollout of a single candidate is a chain of matrix-VECTOR
+// products, for which the 16-column products of large_forward pay sixteen times: here lane r < 32 holds row r of A
+// in registers, lane 32 + r row r of W, and every lane forms its row's 32-term chain acc = fma(M[r][k], x[k], acc),
+// k ascending from acc = 0 -- term for term the chain the matrix instruction forms for column 0 (so the same bits);
+// beside it runs the chain of row (lane & 7) of K_t (x_new - x).  The state and its difference to the old
+// trajectory go through LDS (every lane reads all 32 of each, one address per read); K_t, and per lane its elements
+// of the old controls, k_t and the old next state, are fetched RL_D steps ahead into registers (K_t then passes
+// through LDS, one step ahead, so that a lane can read its row).  u = (u_old + alpha k) + K dx is the same on all
+// lanes with the same (lane & 7); B u takes it from lanes 0..7; c phi(W x) moves from lane 32 + r to lane r.
+constexpr int RL_D = 6; // (even: the LDS buffers alternate with the step's parity)
+
+struct alignas(16) RollMem { // lives in WaveMem::P1, which is free outside the backward sweep
+    double xh[2][LN], dxh[2][LN];
+    double Kb[2][LM * (LN + 2)]; // rows 34 doubles apart: 16-byte aligned, and 8 rows on 8 x 4 different banks
+};
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ void large_forward_first(const LargeP& P, WaveMem& S, const double* xs, const double* us, const double* k,
+                                    const double* K, double alpha, double* xs_new, double* us_new)
+{
+    static_assert(sizeof(RollMem) <= sizeof(S.P1) && RL_D % 2 == 0, "");
+    RollMem& R = *reinterpret_cast<RollMem*>(&S.P1[0][0]);
+    const int lane = threadIdx.x & 63;
+    const int row = lane & 31, a = lane & 7;
+    const int T = P.T;
+    double Mrow[LN], Brow[LM];
+    {
+        const d2* mp = reinterpret_cast<const d2*>((lane >= 32 ? P.W : P.A) + row * LN);
+#pragma unroll
+        for (int q = 0; q < LN / 2; ++q) {
+            const d2 v = mp[q];
+            Mrow[2 * q] = v.x;
+            Mrow[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for (int q = 0; q < LM; ++q)
+            Brow[q] = P.B[row * LM + q];
+    }
+    struct KStage {
+        d2 k0, k1; // elements 4 lane .. 4 lane + 3 of K_t (row-major 8 x 32)
+    };
+    struct VStage {
+        double xo, uo, kk; // x_old[t + 1][row], u_old[t][a], k[t][a]
+    };
+    KStage Ks[RL_D];
+    VStage Vs[RL_D];
+    auto fetch_K = [&](KStage& st, int t) {
+        const int tc = t < T ? t : T - 1;
+        const d2* kp = reinterpret_cast<const d2*>(K + (size_t)tc * LM * LN) + 2 * lane;
+        st.k0 = kp[0];
+        st.k1 = kp[1];
+    };
+    auto fetch_V = [&](VStage& st, int t) {
+        const int tc = t < T ? t : T - 1;
+        st.xo = xs[(size_t)(tc + 1) * LN + row];
+        st.uo = us[(size_t)tc * LM + a];
+        st.kk = k[(size_t)tc * LM + a];
+    };
+    auto put_K = [&](const KStage& st, int buf) { // element e = 4 lane of the 8 x 32 matrix -> row e / 32, column e % 32
+        d2* dst = reinterpret_cast<d2*>(&R.Kb[buf][(lane >> 3) * (LN + 2) + 4 * (lane & 7)]);
+        dst[0] = st.k0;
+        dst[1] = st.k1;
+    };
+#pragma unroll
+    for (int j = 0; j < RL_D; ++j) {
+        fetch_K(Ks[j], j);
+        fetch_V(Vs[j], j);
+    }
+    double xme = xs[row]; // x_new[0] = x_old[0]
+    wave_sync();          // (the backward sweep's last use of this LDS is over)
+    if (lane < LN) {
+        R.xh[0][row] = xme;
+        R.dxh[0][row] = xme - xs[row];
+        xs_new[row] = xme;
+    }
+    put_K(Ks[0], 0);
+    fetch_K(Ks[0], RL_D);
+    wave_sync();
+    auto step = [&](int t, int par, KStage& kn, VStage& vs) {
+        // K of the next step into the other buffer, and the fetch of the step RL_D after it
+        put_K(kn, par ^ 1);
+        fetch_K(kn, t + 1 + RL_D);
+        const d2* xv = reinterpret_cast<const d2*>(R.xh[par]);
+        const d2* dv = reinterpret_cast<const d2*>(R.dxh[par]);
+        const d2* kr = reinterpret_cast<const d2*>(&R.Kb[par][a * (LN + 2)]);
+        double accM = 0.0, accK = 0.0; // (A x)[row] or (W x)[row]; (K dx)[a]
+#pragma unroll
+        for (int q = 0; q < LN / 2; ++q) {
+            const d2 x2 = xv[q], dx2 = dv[q], k2 = kr[q];
+            accM = fma(Mrow[2 * q], x2.x, accM);
+            accK = fma(k2.x, dx2.x, accK);
+            accM = fma(Mrow[2 * q + 1], x2.y, accM);
+            accK = fma(k2.y, dx2.y, accK);
+        }
+        // u_new = u + alpha k + K (x_new - x)   (:104, never clamped)
+        const double u = (vs.uo + alpha * vs.kk) + accK;
+        double bu = 0.0;
+#pragma unroll
+        for (int q = 0; q < LM; ++q)
+            bu = fma(Brow[q], rl64(u, q), bu);
+        // x+ = x + dt (A x + B u + c phi(W x)), phi(z) = z / sqrt(1 + z z): formed where W x is (lanes 32..63)
+        const double sq = 1.0 + accM * accM;
+        const double cphi = P.sig_c * (accM / sqrt(sq));
+        const double cphi_r = __shfl_xor(cphi, 32);
+        const double xn = xme + P.dt * ((accM + bu) + cphi_r);
+        if (lane < LN) {
+            R.xh[par ^ 1][row] = xn;
+            R.dxh[par ^ 1][row] = xn - vs.xo;
+            xs_new[(size_t)(t + 1) * LN + row] = xn;
+        }
+        if (lane < LM)
+            us_new[(size_t)t * LM + a] = u;
+        xme = xn;
+        fetch_V(vs, t + RL_D);
+        wave_sync();
+    };
+    for (int t0 = 0; t0 < T; t0 += RL_D) {
+#pragma unroll
+        for (int j = 0; j < RL_D; ++j)
+            if (t0 + j < T)
+                step(t0 + j, j & 1, Ks[(j + 1) % RL_D], Vs[j]);
+    }
+    wave_sync();
+}
+#endif
+
 // _trajectory_cost (ilqr_core.py:230-239) of a stored trajectory: the stage costs of 16 time steps at a time, the
 // 16 steps as the columns of the same products a rollout forms per step for its 16 step sizes (so each l_t has the
 // bits the rollout would give it), then J = J + l_t in the order of t, and the terminal cost.  The same number on
@@ -1592,9 +1721,13 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
             // the first step size, accepted in > 90 % of the iterations: its rollout without the cost products, its
             // cost from the stored trajectory (large_traj_cost: the same bits); only if it is turned down do the
             // candidates get rolled out with their costs, below (the scan then starts again at the first step size)
+#ifdef ILQR_LARGE_USER_MODEL
             const double a = L.c < O.n_alpha ? O.alphas[L.c] : 0.0;
             large_forward<false, PATH, false>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], a, 0, xsb[nxt],
                                               usb[nxt]);
+#else
+            large_forward_first(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], O.alphas[0], xsb[nxt], usb[nxt]);
+#endif
             wave_sync();
             Jnew = large_traj_cost<PATH>(P, S, xsb[nxt], usb[nxt]);
             const double alpha = O.alphas[0];
