@@ -105,11 +105,12 @@ struct XlBw {
 };
 
 struct XlFwWave { // a rollout of one wavefront
-    double xn[XN], dv[XN], acc[XN], un[XM], ud[XM];
+    double xn[XN], dv[XN], dg[2][XN], acc[XN], un[XM], ud[XM], acu[XM];
+    double Kst[XM * LDN]; // K_t of the step in hand
 };
 
 struct XlFw { // the rollouts of a line search: the model transposed (a lane per row reads consecutive words)
-    double At[XN * LDN], Wt[XN * LDN], Qr[XN * LDN], Bt[XM * LDN];
+    double At[XN * LDN], Wt[XN * LDN], Qr[XN * LDN], Bt[XM * LDN], Rr[XM * LDM];
     XlFwWave wv[4];
 };
 
@@ -236,6 +237,18 @@ __device__ __forceinline__ double xl_rl(double v, int lane)
     return r;
 }
 // a condition that is the same on every lane, as a scalar (keeps the control flow around it wave-uniform)
+__device__ __forceinline__ unsigned long long xl_uni_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <class T>
+__device__ __forceinline__ T* xl_uni_ptr(T* p)
+{
+    return reinterpret_cast<T*>(xl_uni_u64(reinterpret_cast<unsigned long long>(p)));
+}
+
 __device__ __forceinline__ bool xl_uni(bool c) { return __builtin_amdgcn_readfirstlane(c ? 1 : 0) != 0; }
 
 struct XlFac {
@@ -792,15 +805,15 @@ __device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem&
     double* const K0 = K;
     for (int i = T - 1; i >= 0; --i) {
         const int p = i & 1;
-        // The model and the arrays as this step sees them: the pointers are made opaque once per step, so that the
-        // addresses (and loop-invariant loads) the compiler derives from them are formed where they are used instead
-        // of being kept -- hundreds of registers' worth -- across the steps.
+        // The arrays as this step sees them: their pointers are made opaque once per step, so that the addresses the
+        // compiler derives from them are formed where they are used instead of being kept -- hundreds of registers'
+        // worth -- across the steps.  (The model's pointers are left alone: with them in the list the backend could
+        // not always keep them in scalar registers, and the sweep is no slower without.)
         XlP P = P0;
         const double* xs = xs0;
         const double* us = us0;
         double* k = k0;
         double* K = K0;
-        asm volatile("" : "+s"(P.A), "+s"(P.W), "+s"(P.Q), "+s"(P.R), "+s"(P.lower), "+s"(P.upper), "+s"(P.xg), "+s"(P.ug));
         asm volatile("" : "+s"(xs), "+s"(us), "+s"(k), "+s"(K));
         // (the same for what is derived from the lane index, the LDS addresses of every tile: afresh in every phase)
         int lane, g, c;
@@ -1020,6 +1033,8 @@ __device__ void xl_forward_load(const XlP& P, XlMem& S)
     }
     for (int e = threadIdx.x; e < n * m; e += 256)
         F.Bt[(e % m) * LDN + e / m] = P.B[e];
+    for (int e = threadIdx.x; e < m * m; e += 256)
+        F.Rr[(e / m) * LDM + e % m] = P.R[e];
     __syncthreads();
 }
 
@@ -1044,85 +1059,224 @@ __device__ __forceinline__ double xl_quad(int len, const double* v, const double
 // One rollout by one wavefront.  k == nullptr: _dynamics_rollout + _trajectory_cost (ilqr_core.py:69-83, :230-239)
 // of the controls `us`; else _forward_pass (:85-107) with step size alpha around (xs, us), no clamp on the new
 // controls, plus the cost.  xs_new / us_new may be null (nothing stored).  Returns J (the same number on every lane).
+//
+// A step is two stretches of straight-line code with a wavefront barrier after each.  In the first, lane r forms the
+// chains of row r of A x, W x and of column r of x_diff^T Q, and lane a < m the chain of row a of K (x_new - x) --
+// four independent chains side by side, eight terms per round of LDS reads; in the second B u, the cost's chains
+// over the columns and the new state.  What a step reads from memory -- the old state, control, k and column `lane`
+// of K_t (which passes through LDS so that a lane can read its row), the goals of a path cost -- is fetched two to
+// three steps ahead into registers.  Every chain has the reference's terms in the reference's order.
 template <bool PATH>
 __device__ double xl_forward(const XlP& P, XlMem& S, const double* __restrict__ xs, const double* __restrict__ us,
                              const double* __restrict__ k, const double* __restrict__ K, const double* __restrict__ x0,
                              double alpha, double* __restrict__ xs_new, double* __restrict__ us_new)
 {
+    // (the arguments are the same on all lanes of the wavefront, but derived from its index: as scalars, every
+    // address below is a scalar base plus the lane's offset)
+    xs = xl_uni_ptr(xs);
+    us = xl_uni_ptr(us);
+    k = xl_uni_ptr(k);
+    K = xl_uni_ptr(K);
+    x0 = xl_uni_ptr(x0);
+    xs_new = xl_uni_ptr(xs_new);
+    us_new = xl_uni_ptr(us_new);
+    alpha = __longlong_as_double((long long)xl_uni_u64((unsigned long long)__double_as_longlong(alpha)));
     XlFw& F = S.fw;
     const int n = P.n, m = P.m, T = P.T;
     const int lane = threadIdx.x & 63;
-    XlFwWave& V = F.wv[threadIdx.x >> 6];
+    XlFwWave& V = F.wv[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+    const bool fb = k != nullptr;
+    const int ln = lane < n ? lane : n - 1, lm = lane < m ? lane : m - 1; // (lanes beyond n / m repeat the last one)
     const double half = PATH ? 1.0 : 0.5;
-    double xn = 0.0;
-    if (lane < n) {
-        xn = x0[lane];
-        V.xn[lane] = xn;
-        if (xs_new)
-            xs_new[lane] = xn;
-    }
+    struct Ops { // what step t reads from memory, per lane
+        double xo, xg, uo, kk, ug;
+        double Kc[XM]; // column ln of K_t
+    };
+    const double xg0 = PATH ? 0.0 : P.xg[ln], ug0 = PATH ? 0.0 : P.ug[lm];
+    auto fetch = [&](Ops& o, int t) {
+        const int64_t tc = t < T ? t : T - 1;
+        o.uo = us[tc * m + lm];
+        o.xg = PATH ? P.xg[tc * n + ln] : xg0;
+        o.ug = PATH ? P.ug[tc * m + lm] : ug0;
+        if (fb) {
+            o.xo = xs[tc * n + ln];
+            o.kk = k[tc * m + lm];
+#pragma unroll
+            for (int a = 0; a < XM; ++a)
+                o.Kc[a] = a < m ? K[(tc * m + a) * n + ln] : 0.0;
+        } else {
+            o.xo = 0.0;
+            o.kk = 0.0;
+        }
+    };
+    auto put = [&](const Ops& o, double xn, int par) { // the LDS operands of a step whose state is xn
+        if (lane < n) {
+            V.xn[lane] = xn;
+            V.dv[lane] = xn - o.xo;
+            V.dg[par][lane] = xn - o.xg;
+            if (fb) {
+#pragma unroll
+                for (int a = 0; a < XM; ++a)
+                    if (a < m)
+                        V.Kst[a * LDN + lane] = o.Kc[a];
+            }
+        }
+    };
+    Ops oa, ob, oc;
+    fetch(oa, 0);
+    fetch(ob, 1);
+    fetch(oc, 2);
+    double xn = x0[ln];
+    if (lane < n && xs_new)
+        xs_new[lane] = xn;
+    xl_wave_sync();
+    put(oa, xn, 0);
     xl_wave_sync();
     double J = 0.0;
-    for (int i = 0; i < T; ++i) {
-        const double* xg = PATH ? P.xg + (int64_t)i * n : P.xg;
-        const double* ug = PATH ? P.ug + (int64_t)i * m : P.ug;
-        double un = 0.0;
-        if (k != nullptr) {
-            if (lane < n)
-                V.dv[lane] = xn - xs[(int64_t)i * n + lane];
-            xl_wave_sync();
-            if (lane < m) {
-                const double* Kr = K + ((int64_t)i * m + lane) * n;
-                double acc = Kr[0] * V.dv[0];
-                for (int a = 1; a < n; ++a)
-                    acc = fma(Kr[a], V.dv[a], acc);
-                un = (us[(int64_t)i * m + lane] + alpha * k[(int64_t)i * m + lane]) + acc;
+    // `mine`: the operands of step i; `next`: those of step i + 1; `mine` is fetched again for step i + 3
+    auto step = [&](int i, int par, Ops& mine, const Ops& next) {
+        const double* xv = V.xn;
+        const double* dv = V.dv;
+        const double* dg = V.dg[par];
+        const double* At = F.At + lane;
+        const double* Wt = F.Wt + lane;
+        const double* Qr = F.Qr + lane;
+        const double* Kr = V.Kst + lm * LDN;
+        double ax = 0.0, z = 0.0, cq = 0.0, kd = 0.0;
+        int j0 = 0;
+#pragma unroll 2
+        for (; j0 + 8 <= n; j0 += 8) {
+            double a_[8], w_[8], q_[8], k_[8], x_[8], d_[8], g_[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                a_[q] = At[(j0 + q) * LDN];
+                w_[q] = Wt[(j0 + q) * LDN];
+                q_[q] = Qr[(j0 + q) * LDN];
+                k_[q] = Kr[j0 + q];
+                x_[q] = xv[j0 + q];
+                d_[q] = dv[j0 + q];
+                g_[q] = dg[j0 + q];
             }
-            xl_wave_sync();
-        } else if (lane < m) {
-            un = us[(int64_t)i * m + lane];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool first = q == 0 && j0 == 0; // (a chain starts with a product, not with fma(., ., 0))
+                ax = first ? a_[q] * x_[q] : fma(a_[q], x_[q], ax);
+                z = first ? w_[q] * x_[q] : fma(w_[q], x_[q], z);
+                cq = first ? g_[q] * q_[q] : fma(g_[q], q_[q], cq);
+                kd = first ? k_[q] * d_[q] : fma(k_[q], d_[q], kd);
+            }
         }
+        for (; j0 < n; ++j0) {
+            const double a = At[j0 * LDN], w = Wt[j0 * LDN], qq = Qr[j0 * LDN], kk = Kr[j0];
+            const double x = xv[j0], d = dv[j0], g = dg[j0];
+            ax = j0 == 0 ? a * x : fma(a, x, ax);
+            z = j0 == 0 ? w * x : fma(w, x, z);
+            cq = j0 == 0 ? g * qq : fma(g, qq, cq);
+            kd = j0 == 0 ? kk * d : fma(kk, d, kd);
+        }
+        // u_new = u + alpha k + K (x_new - x)   (:104, never clamped), or the given control
+        const double un = fb ? (mine.uo + alpha * mine.kk) + kd : mine.uo;
         if (lane < m) {
             V.un[lane] = un;
-            V.ud[lane] = un - ug[lane];
+            V.ud[lane] = un - mine.ug;
             if (us_new)
                 us_new[(int64_t)i * m + lane] = un;
         }
         if (lane < n)
-            V.dv[lane] = xn - xg[lane];
+            V.acc[lane] = cq;
         xl_wave_sync();
-        // l(x, u) (ilqr_cost.py:532-553; PathQRCost :682-701 without the 1/2)
-        double sx = xl_quad(n, V.dv, F.Qr, LDN, V.acc, lane);
-        if (!PATH)
-            sx = sx * half;
-        double su = xl_quad(m, V.ud, P.R, m, V.acc, lane);
-        if (!PATH)
-            su = su * half;
-        J = J + (sx + su);
-        // x+ = x + dt ((A x + B u) + c phi(W x))
-        double xnext = 0.0;
-        if (lane < n) {
-            double ax = F.At[0 * LDN + lane] * V.xn[0], z = F.Wt[0 * LDN + lane] * V.xn[0];
-            for (int j = 1; j < n; ++j) {
-                ax = fma(F.At[j * LDN + lane], V.xn[j], ax);
-                z = fma(F.Wt[j * LDN + lane], V.xn[j], z);
+        // B u; x_diff^T Q x_diff as (x_diff^T Q) . x_diff; column lm of u_diff^T R
+        const double* Bt = F.Bt + lane;
+        const double* Rr = F.Rr + lm;
+        double bu = 0.0, cu = 0.0;
+        {
+            int j = 0;
+            for (; j + 8 <= m; j += 8) {
+                double b_[8], u_[8], d_[8], r_[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    b_[q] = Bt[(j + q) * LDN];
+                    u_[q] = V.un[j + q];
+                    d_[q] = V.ud[j + q];
+                    r_[q] = Rr[(j + q) * LDM];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool first = q == 0 && j == 0;
+                    bu = first ? b_[q] * u_[q] : fma(b_[q], u_[q], bu);
+                    cu = first ? d_[q] * r_[q] : fma(d_[q], r_[q], cu);
+                }
             }
-            double bu = F.Bt[0 * LDN + lane] * V.un[0];
-            for (int j = 1; j < m; ++j)
-                bu = fma(F.Bt[j * LDN + lane], V.un[j], bu);
-            const double s = 1.0 + z * z;
-            const double phi = z / sqrt(s);
-            xnext = xn + P.dt * ((ax + bu) + P.sig_c * phi);
+            for (; j < m; ++j) {
+                bu = j == 0 ? Bt[j * LDN] * V.un[j] : fma(Bt[j * LDN], V.un[j], bu);
+                cu = j == 0 ? V.ud[j] * Rr[j * LDM] : fma(V.ud[j], Rr[j * LDM], cu);
+            }
         }
-        xl_wave_sync();
-        if (lane < n) {
-            xn = xnext;
-            V.xn[lane] = xn;
-            if (xs_new)
-                xs_new[(int64_t)(i + 1) * n + lane] = xn;
+        double sx = V.acc[0] * dg[0];
+        j0 = 1;
+        if (n >= 8) {
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+                sx = fma(V.acc[q], dg[q], sx);
+            for (j0 = 8; j0 + 8 <= n; j0 += 8) {
+                double c_[8], g_[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    c_[q] = V.acc[j0 + q];
+                    g_[q] = dg[j0 + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    sx = fma(c_[q], g_[q], sx);
+            }
         }
+        for (; j0 < n; ++j0)
+            sx = fma(V.acc[j0], dg[j0], sx);
+        // x+ = x + dt ((A x + B u) + c phi(W x))
+        const double s = 1.0 + z * z;
+        const double phi = z / sqrt(s);
+        xn = xn + P.dt * ((ax + bu) + P.sig_c * phi);
+        if (lane < m)
+            V.acu[lane] = cu;
+        if (lane < n && xs_new)
+            xs_new[(int64_t)(i + 1) * n + lane] = xn;
+        put(next, xn, par ^ 1);
         xl_wave_sync();
+        double su = 0.0;
+        {
+            int j = 0;
+            for (; j + 8 <= m; j += 8) {
+                double c_[8], d_[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    c_[q] = V.acu[j + q];
+                    d_[q] = V.ud[j + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    su = (q == 0 && j == 0) ? c_[q] * d_[q] : fma(c_[q], d_[q], su);
+            }
+            for (; j < m; ++j)
+                su = j == 0 ? V.acu[j] * V.ud[j] : fma(V.acu[j], V.ud[j], su);
+        }
+        // l(x, u) (ilqr_cost.py:532-553; PathQRCost :682-701 without the 1/2)
+        if (!PATH) {
+            sx = sx * half;
+            su = su * half;
+        }
+        J = J + (sx + su);
+        asm volatile("" : "+v"(J)); // (the same on every lane, but it lives in a vector register)
+        fetch(mine, i + 3);
+    };
+    for (int i0 = 0; i0 < T; i0 += 6) { // (six = two rounds of the three operand sets: the parity stays a constant)
+        if (i0 + 0 < T) step(i0 + 0, 0, oa, ob);
+        if (i0 + 1 < T) step(i0 + 1, 1, ob, oc);
+        if (i0 + 2 < T) step(i0 + 2, 0, oc, oa);
+        if (i0 + 3 < T) step(i0 + 3, 1, oa, ob);
+        if (i0 + 4 < T) step(i0 + 4, 0, ob, oc);
+        if (i0 + 5 < T) step(i0 + 5, 1, oc, oa);
     }
+    xl_wave_sync();
     {
         const double* xg = PATH ? P.xg + (int64_t)T * n : P.xg;
         if (lane < n)
@@ -1308,7 +1462,7 @@ __device__ void xl_solve_one(const XlP& P_batch, const XlSolveOpts& O, XlMem& S,
             if (mu <= O.mu_min)
                 mu = 0.0;
             J = Jnew;
-            cur = win < cur ? win : win + 1;
+            cur = __builtin_amdgcn_readfirstlane(win < cur ? win : win + 1); // (a scalar: it selects the buffers)
             if (actual < O.tol)
                 converged = 1;
         } else {

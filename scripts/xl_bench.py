@@ -15,6 +15,8 @@ def main():
     import torch
     from ilqr_amd import _hip
     from ilqr_amd.synthetic import SyntheticWorkload
+    if os.environ.get("ILQR_LIB"):  # A/B of differently compiled builds: ILQR_LIB=build/variant.so
+        _hip.LIB_PATH = os.path.abspath(os.environ["ILQR_LIB"])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
