@@ -102,6 +102,23 @@ def test_large_solve_bit_exact(hip):
     assert (ref["trace"]["n_clamped"] > 0).any() and (ref["status"] == 1).any()
 
 
+@pytest.mark.parametrize("T", [1, 2, 5, 7, 13])
+def test_large_solve_shortest_horizons(hip, T):
+    """Horizons shorter than, and not a multiple of, the depth to which the first rollout of a line search fetches
+    its operands ahead (and of the 16 time steps the sweeps batch): whole solves, every output against the oracle."""
+    B = 12
+    Mo, M = models(hip, T)
+    x0, us0 = co.synthetic_batch(B, T=T, seed_x=61 + T, seed_u=62 + T)
+    us0 *= 2.0
+    ref = co.solve(Mo, co.Opts(max_iter=12), x0, us0, nthreads=4)
+    out = hip.large_solve(M, hip.Opts(max_iter=12), dev(x0), dev(us0))
+    torch.cuda.synchronize()
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+
+
 def test_large_solve_more_problems_than_wavefronts(hip):
     """The solve kernel keeps one workgroup per CU resident and hands problems out from a queue: with more
     problems than the chip has wavefront slots every wavefront solves several, one after the other, and

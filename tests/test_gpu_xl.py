@@ -89,6 +89,28 @@ def test_wide_path_bit_exact(hip, n, m):
     assert (ref["trace"]["n_clamped"] > 0).any()
 
 
+@pytest.mark.parametrize("T", [1, 2, 4, 7])
+def test_wide_path_shortest_horizons(hip, T):
+    """Horizons shorter than, and not a multiple of, the depth to which a rollout fetches its operands ahead: whole
+    solves and a line search with a stored candidate, for a size with ragged blocks of eight (n = 45, m = 11)."""
+    n, m, B = 45, 11, 9
+    Mo, M = pair(hip, n, m, T, wide=True)
+    x0, us0 = co.synthetic_batch(B, n=n, m=m, T=T, seed_x=70 + T, seed_u=80 + T)
+    us0 *= 2.0
+    xs_ref, J_ref = co.rollout_cost(Mo, x0, us0)
+    xs, J = hip.large_rollout_cost(M, dev(x0), dev(us0))
+    assert eq(xs.cpu().numpy(), xs_ref) and eq(J.cpu().numpy(), J_ref)
+    bw_ref = co.backward(Mo, co.Opts(), xs_ref, us0, np.full(B, 1.0))
+    al = co.Opts().alphas[:6]
+    xs_f, us_f, J_f = co.forward(Mo, al, xs_ref, us0, bw_ref["k"], bw_ref["K"])
+    Jg, xg, ug = hip.large_forward_ls(M, al, dev(xs_ref), dev(us0), dev(bw_ref["k"]), dev(bw_ref["K"]), store_idx=5)
+    assert eq(Jg.cpu().numpy(), J_f) and eq(xg.cpu().numpy(), xs_f[:, 5]) and eq(ug.cpu().numpy(), us_f[:, 5])
+    ref = co.solve(Mo, co.Opts(max_iter=10), x0, us0, nthreads=4)
+    out = hip.large_solve(M, hip.Opts(max_iter=10), dev(x0), dev(us0), trace=True)
+    torch.cuda.synchronize()
+    compare_solve(out, ref, B)
+
+
 @pytest.mark.parametrize("n,m", [(32, 8), (20, 5)])
 def test_wide_path_equals_the_register_path(hip, n, m):
     """Where both kernel families apply they return the same bits: the model solved on the register-resident
