@@ -1392,18 +1392,31 @@ struct alignas(16) RollMem { // lives in WaveMem::P1, which is free outside the 
 };
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+// The trajectory and gain arrays reach the solver through run-time selected pointers, which the compiler can only
+// treat as generic: generic loads count as LDS operations as well, so every wait for an LDS read would also wait for
+// the fetches that are meant to stay in flight for six steps.  Here they are said to be global memory.
+typedef const double __attribute__((address_space(1))) * GlobalIn;
+typedef const d2 __attribute__((address_space(1))) * GlobalIn2;
+typedef double __attribute__((address_space(1))) * GlobalOut;
 
-__device__ void large_forward_first(const LargeP& P, WaveMem& S, const double* xs, const double* us, const double* k,
+// (not inlined: with registers of its own, free of the solver's, nothing of it is spilled -- a reload from scratch
+// in the step would make the wait for it a wait for every fetch in flight)
+__device__ __noinline__ void large_forward_first(const LargeP& P, WaveMem& S, const double* xs, const double* us, const double* k,
                                     const double* K, double alpha, double* xs_new, double* us_new)
 {
     static_assert(sizeof(RollMem) <= sizeof(S.P1) && RL_D % 2 == 0, "");
-    RollMem& R = *reinterpret_cast<RollMem*>(&S.P1[0][0]);
+    // (S arrives as a generic reference; said to be LDS, the accesses below are LDS instructions)
+    typedef RollMem __attribute__((address_space(3))) LdsRollMem;
+    LdsRollMem& R = *(LdsRollMem*)(&S.P1[0][0]);
     const int lane = threadIdx.x & 63;
     const int row = lane & 31, a = lane & 7;
     const int T = P.T;
+    const GlobalIn xs_g = (GlobalIn)xs, us_g = (GlobalIn)us, k_g = (GlobalIn)k;
+    const GlobalIn2 K_g = (GlobalIn2)K;
+    const GlobalOut xs_o = (GlobalOut)xs_new, us_o = (GlobalOut)us_new;
     double Mrow[LN], Brow[LM];
     {
-        const d2* mp = reinterpret_cast<const d2*>((lane >= 32 ? P.W : P.A) + row * LN);
+        const GlobalIn2 mp = (GlobalIn2)((lane >= 32 ? P.W : P.A) + row * LN);
 #pragma unroll
         for (int q = 0; q < LN / 2; ++q) {
             const d2 v = mp[q];
@@ -1412,7 +1425,7 @@ __device__ void large_forward_first(const LargeP& P, WaveMem& S, const double* x
         }
 #pragma unroll
         for (int q = 0; q < LM; ++q)
-            Brow[q] = P.B[row * LM + q];
+            Brow[q] = ((GlobalIn)P.B)[row * LM + q];
     }
     struct KStage {
         d2 k0, k1; // elements 4 lane .. 4 lane + 3 of K_t (row-major 8 x 32)
@@ -1424,32 +1437,38 @@ __device__ void large_forward_first(const LargeP& P, WaveMem& S, const double* x
     VStage Vs[RL_D];
     auto fetch_K = [&](KStage& st, int t) {
         const int tc = t < T ? t : T - 1;
-        const d2* kp = reinterpret_cast<const d2*>(K + (size_t)tc * LM * LN) + 2 * lane;
+        const GlobalIn2 kp = K_g + (size_t)tc * (LM * LN / 2) + 2 * lane;
         st.k0 = kp[0];
         st.k1 = kp[1];
     };
     auto fetch_V = [&](VStage& st, int t) {
         const int tc = t < T ? t : T - 1;
-        st.xo = xs[(size_t)(tc + 1) * LN + row];
-        st.uo = us[(size_t)tc * LM + a];
-        st.kk = k[(size_t)tc * LM + a];
+        st.xo = xs_g[(size_t)(tc + 1) * LN + row];
+        st.uo = us_g[(size_t)tc * LM + a];
+        st.kk = k_g[(size_t)tc * LM + a];
     };
     auto put_K = [&](const KStage& st, int buf) { // element e = 4 lane of the 8 x 32 matrix -> row e / 32, column e % 32
-        d2* dst = reinterpret_cast<d2*>(&R.Kb[buf][(lane >> 3) * (LN + 2) + 4 * (lane & 7)]);
+        typedef d2 __attribute__((address_space(3))) LdsD2;
+        LdsD2* dst = (LdsD2*)(&R.Kb[buf][(lane >> 3) * (LN + 2) + 4 * (lane & 7)]);
         dst[0] = st.k0;
         dst[1] = st.k1;
     };
+    double xme = xs_g[row]; // x_new[0] = x_old[0]
+    const double dt = P.dt, sig_c = P.sig_c;
+    // Everything loaded so far is waited for HERE (vmcnt(0)), before the fetches that stay in flight are issued:
+    // a value still pending at the head of the step loop would be waited for in every step, and a wait for the
+    // oldest load is a wait for all of them.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
     for (int j = 0; j < RL_D; ++j) {
         fetch_K(Ks[j], j);
         fetch_V(Vs[j], j);
     }
-    double xme = xs[row]; // x_new[0] = x_old[0]
-    wave_sync();          // (the backward sweep's last use of this LDS is over)
+    wave_sync(); // (the backward sweep's last use of this LDS is over)
     if (lane < LN) {
         R.xh[0][row] = xme;
-        R.dxh[0][row] = xme - xs[row];
-        xs_new[row] = xme;
+        R.dxh[0][row] = xme - xs_g[row];
+        xs_o[row] = xme;
     }
     put_K(Ks[0], 0);
     fetch_K(Ks[0], RL_D);
@@ -1458,9 +1477,10 @@ __device__ void large_forward_first(const LargeP& P, WaveMem& S, const double* x
         // K of the next step into the other buffer, and the fetch of the step RL_D after it
         put_K(kn, par ^ 1);
         fetch_K(kn, t + 1 + RL_D);
-        const d2* xv = reinterpret_cast<const d2*>(R.xh[par]);
-        const d2* dv = reinterpret_cast<const d2*>(R.dxh[par]);
-        const d2* kr = reinterpret_cast<const d2*>(&R.Kb[par][a * (LN + 2)]);
+        typedef const d2 __attribute__((address_space(3))) LdsD2In;
+        LdsD2In* xv = (LdsD2In*)(R.xh[par]);
+        LdsD2In* dv = (LdsD2In*)(R.dxh[par]);
+        LdsD2In* kr = (LdsD2In*)(&R.Kb[par][a * (LN + 2)]);
         double accM = 0.0, accK = 0.0; // (A x)[row] or (W x)[row]; (K dx)[a]
 #pragma unroll
         for (int q = 0; q < LN / 2; ++q) {
@@ -1478,16 +1498,16 @@ __device__ void large_forward_first(const LargeP& P, WaveMem& S, const double* x
             bu = fma(Brow[q], rl64(u, q), bu);
         // x+ = x + dt (A x + B u + c phi(W x)), phi(z) = z / sqrt(1 + z z): formed where W x is (lanes 32..63)
         const double sq = 1.0 + accM * accM;
-        const double cphi = P.sig_c * (accM / sqrt(sq));
+        const double cphi = sig_c * (accM / sqrt(sq));
         const double cphi_r = __shfl_xor(cphi, 32);
-        const double xn = xme + P.dt * ((accM + bu) + cphi_r);
+        const double xn = xme + dt * ((accM + bu) + cphi_r);
         if (lane < LN) {
             R.xh[par ^ 1][row] = xn;
             R.dxh[par ^ 1][row] = xn - vs.xo;
-            xs_new[(size_t)(t + 1) * LN + row] = xn;
+            xs_o[(size_t)(t + 1) * LN + row] = xn;
         }
         if (lane < LM)
-            us_new[(size_t)t * LM + a] = u;
+            us_o[(size_t)t * LM + a] = u;
         xme = xn;
         fetch_V(vs, t + RL_D);
         wave_sync();
