@@ -1693,16 +1693,22 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
     const int T = P.T;
     const LaneId L = lane_id();
     const int lane = threadIdx.x & 63;
-    double* xsb[2] = {xs0 + b * (T + 1) * LN, W.xs1 + b * (T + 1) * LN};
-    double* usb[2] = {us0 + b * T * LM, W.us1 + b * T * LM};
-    double* kb[2] = {k0 + b * T * LM, W.k1 + b * T * LM};
-    double* Kb[2] = {K0 + b * T * LM * LN, W.K1 + b * T * LM * LN};
+    // the two copies of each array: the caller's and the workspace's (selected, not indexed: an array of pointers
+    // indexed at run time lives in scratch memory, and what is loaded back from there is no longer known to be global)
+    double* const xs_a = xs0 + b * (T + 1) * LN, * const xs_b = W.xs1 + b * (T + 1) * LN;
+    double* const us_a = us0 + b * T * LM, * const us_b = W.us1 + b * T * LM;
+    double* const k_a = k0 + b * T * LM, * const k_b = W.k1 + b * T * LM;
+    double* const K_a = K0 + b * T * LM * LN, * const K_b = W.K1 + b * T * LM * LN;
+    auto xsb = [&](int i) { return i ? xs_b : xs_a; };
+    auto usb = [&](int i) { return i ? us_b : us_a; };
+    auto kb = [&](int i) { return i ? k_b : k_a; };
+    auto Kb = [&](int i) { return i ? K_b : K_a; };
     int cur = 0, gcur = 0;
     // us = u_seq_init.copy() ; xs = rollout ; J_opt                     (:269-271)
     for (int i = lane; i < T * LM; i += 64)
-        usb[0][i] = us_init[b * T * LM + i];
+        usb(0)[i] = us_init[b * T * LM + i];
     wave_sync();
-    large_forward<true, PATH>(P, S, nullptr, usb[0], nullptr, nullptr, x0 + b * LN, 0.0, 0, xsb[0], nullptr);
+    large_forward<true, PATH>(P, S, nullptr, usb(0), nullptr, nullptr, x0 + b * LN, 0.0, 0, xsb(0), nullptr);
     double J = S.J[0];
     double mu = O.mu_from_array ? mu_out[b] : 1.0; // reset per call (:264); delta_ persists (:62)
     double delta = delta_io[b];
@@ -1719,7 +1725,7 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
         // backward pass with the LinAlgError retry loop (:287-299); when it gives up at mu_max
         // the line search below still runs on the previous gains and Delta_J terms, as in the reference
         for (;;) {
-            large_backward<PATH, FULL>(P, O.qp, M, S, xsb[cur], usb[cur], mu, kb[gcur ^ 1], Kb[gcur ^ 1], bw, nullptr, nullptr);
+            large_backward<PATH, FULL>(P, O.qp, M, S, xsb(cur), usb(cur), mu, kb(gcur ^ 1), Kb(gcur ^ 1), bw, nullptr, nullptr);
             wave_sync();
             if (bw.rc == 0) {
                 gcur ^= 1;
@@ -1743,13 +1749,13 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
             // candidates get rolled out with their costs, below (the scan then starts again at the first step size)
 #ifdef ILQR_LARGE_USER_MODEL
             const double a = L.c < O.n_alpha ? O.alphas[L.c] : 0.0;
-            large_forward<false, PATH, false>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], a, 0, xsb[nxt],
-                                              usb[nxt]);
+            large_forward<false, PATH, false>(P, S, xsb(cur), usb(cur), kb(gcur), Kb(gcur), xsb(cur), a, 0, xsb(nxt),
+                                              usb(nxt));
 #else
-            large_forward_first(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], O.alphas[0], xsb[nxt], usb[nxt]);
+            large_forward_first(P, S, xsb(cur), usb(cur), kb(gcur), Kb(gcur), O.alphas[0], xsb(nxt), usb(nxt));
 #endif
             wave_sync();
-            Jnew = large_traj_cost<PATH>(P, S, xsb[nxt], usb[nxt]);
+            Jnew = large_traj_cost<PATH>(P, S, xsb(nxt), usb(nxt));
             const double alpha = O.alphas[0];
             const double expected = (alpha * dJ1 + alpha * alpha * dJ2) * -1;
             if (expected <= 0.0) {
@@ -1764,8 +1770,8 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
             for (int pass = 0; pass * LA < O.n_alpha && !ended; ++pass) {
                 int jj = pass * LA + L.c;
                 double a = jj < O.n_alpha ? O.alphas[jj < 32 ? jj : 0] : 0.0;
-                large_forward<false, PATH>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], a, pass == 0 ? 0 : -1,
-                                     xsb[nxt], usb[nxt]);
+                large_forward<false, PATH>(P, S, xsb(cur), usb(cur), kb(gcur), Kb(gcur), xsb(cur), a, pass == 0 ? 0 : -1,
+                                     xsb(nxt), usb(nxt));
                 int win = -1;
                 for (int c = 0; c < LA && pass * LA + c < O.n_alpha; ++c) {
                     j = pass * LA + c;
@@ -1790,8 +1796,8 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
                 if (accepted && !(pass == 0 && win == 0)) {
                     // the accepted candidate's states and controls (same arithmetic, same bits)
                     double aw = O.alphas[pass * LA + L.c < O.n_alpha ? pass * LA + L.c : 0];
-                    large_forward<false, PATH>(P, S, xsb[cur], usb[cur], kb[gcur], Kb[gcur], xsb[cur], aw, win, xsb[nxt],
-                                         usb[nxt]);
+                    large_forward<false, PATH>(P, S, xsb(cur), usb(cur), kb(gcur), Kb(gcur), xsb(cur), aw, win, xsb(nxt),
+                                         usb(nxt));
                 }
             }
         }
@@ -1836,15 +1842,15 @@ __device__ __forceinline__ void large_solve_one(const LargeP& P_batch, const LSo
     // results back into the caller's arrays
     if (cur == 1) {
         for (int i = lane; i < (T + 1) * LN; i += 64)
-            xsb[0][i] = xsb[1][i];
+            xsb(0)[i] = xsb(1)[i];
         for (int i = lane; i < T * LM; i += 64)
-            usb[0][i] = usb[1][i];
+            usb(0)[i] = usb(1)[i];
     }
     if (gcur == 1) {
         for (int i = lane; i < T * LM; i += 64)
-            kb[0][i] = kb[1][i];
+            kb(0)[i] = kb(1)[i];
         for (int i = lane; i < T * LM * LN; i += 64)
-            Kb[0][i] = Kb[1][i];
+            Kb(0)[i] = Kb(1)[i];
     }
     if (lane == 0) {
         delta_io[b] = delta;
