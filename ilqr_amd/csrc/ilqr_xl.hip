@@ -1081,6 +1081,16 @@ __device__ double xl_forward(const XlP& P, XlMem& S, const double* __restrict__ 
     xs_new = xl_uni_ptr(xs_new);
     us_new = xl_uni_ptr(us_new);
     alpha = __longlong_as_double((long long)xl_uni_u64((unsigned long long)__double_as_longlong(alpha)));
+    // Where the compiler keeps this function out of line, S and the arrays are generic pointers to it, and a generic
+    // access is slower than an LDS or a global one and counts as both when waited for: S is said to be LDS, the
+    // arrays are said to be global memory.
+#if defined(__HIP_DEVICE_COMPILE__) // (the builtin exists in the device pass only)
+    __builtin_assume(__builtin_amdgcn_is_shared((const void*)&S));
+#endif
+    typedef const double __attribute__((address_space(1))) * GIn;
+    typedef double __attribute__((address_space(1))) * GOut;
+    const GIn xs_g = (GIn)xs, us_g = (GIn)us, k_g = (GIn)k, K_g = (GIn)K, xg_g = (GIn)P.xg, ug_g = (GIn)P.ug;
+    const GOut xs_o = (GOut)xs_new, us_o = (GOut)us_new;
     XlFw& F = S.fw;
     const int n = P.n, m = P.m, T = P.T;
     const int lane = threadIdx.x & 63;
@@ -1092,18 +1102,18 @@ __device__ double xl_forward(const XlP& P, XlMem& S, const double* __restrict__ 
         double xo, xg, uo, kk, ug;
         double Kc[XM]; // column ln of K_t
     };
-    const double xg0 = PATH ? 0.0 : P.xg[ln], ug0 = PATH ? 0.0 : P.ug[lm];
+    const double xg0 = PATH ? 0.0 : xg_g[ln], ug0 = PATH ? 0.0 : ug_g[lm];
     auto fetch = [&](Ops& o, int t) {
         const int64_t tc = t < T ? t : T - 1;
-        o.uo = us[tc * m + lm];
-        o.xg = PATH ? P.xg[tc * n + ln] : xg0;
-        o.ug = PATH ? P.ug[tc * m + lm] : ug0;
+        o.uo = us_g[tc * m + lm];
+        o.xg = PATH ? xg_g[tc * n + ln] : xg0;
+        o.ug = PATH ? ug_g[tc * m + lm] : ug0;
         if (fb) {
-            o.xo = xs[tc * n + ln];
-            o.kk = k[tc * m + lm];
+            o.xo = xs_g[tc * n + ln];
+            o.kk = k_g[tc * m + lm];
 #pragma unroll
             for (int a = 0; a < XM; ++a)
-                o.Kc[a] = a < m ? K[(tc * m + a) * n + ln] : 0.0;
+                o.Kc[a] = a < m ? K_g[(tc * m + a) * n + ln] : 0.0;
         } else {
             o.xo = 0.0;
             o.kk = 0.0;
@@ -1122,13 +1132,18 @@ __device__ double xl_forward(const XlP& P, XlMem& S, const double* __restrict__ 
             }
         }
     };
+    double xn = ((GIn)x0)[ln];
+    const double dt = P.dt, sig_c = P.sig_c;
+    // Everything loaded so far is waited for here (vmcnt(0)), before the fetches that stay in flight are issued: a
+    // value still pending at the head of the step loop would be waited for in every trip, and a wait for the oldest
+    // load is a wait for all of them.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     Ops oa, ob, oc;
     fetch(oa, 0);
     fetch(ob, 1);
     fetch(oc, 2);
-    double xn = x0[ln];
     if (lane < n && xs_new)
-        xs_new[lane] = xn;
+        xs_o[lane] = xn;
     xl_wave_sync();
     put(oa, xn, 0);
     xl_wave_sync();
@@ -1180,7 +1195,7 @@ __device__ double xl_forward(const XlP& P, XlMem& S, const double* __restrict__ 
             V.un[lane] = un;
             V.ud[lane] = un - mine.ug;
             if (us_new)
-                us_new[(int64_t)i * m + lane] = un;
+                us_o[(int64_t)i * m + lane] = un;
         }
         if (lane < n)
             V.acc[lane] = cq;
@@ -1235,11 +1250,11 @@ __device__ double xl_forward(const XlP& P, XlMem& S, const double* __restrict__ 
         // x+ = x + dt ((A x + B u) + c phi(W x))
         const double s = 1.0 + z * z;
         const double phi = z / sqrt(s);
-        xn = xn + P.dt * ((ax + bu) + P.sig_c * phi);
+        xn = xn + dt * ((ax + bu) + sig_c * phi);
         if (lane < m)
             V.acu[lane] = cu;
         if (lane < n && xs_new)
-            xs_new[(int64_t)(i + 1) * n + lane] = xn;
+            xs_o[(int64_t)(i + 1) * n + lane] = xn;
         put(next, xn, par ^ 1);
         xl_wave_sync();
         double su = 0.0;
