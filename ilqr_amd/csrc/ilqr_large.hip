@@ -1545,6 +1545,12 @@ __device__ double large_traj_cost(const LargeP& P, WaveMem& S, const double* xs,
     xg[1] = load_v(P.xg, LN, 1, L);
     const bool diag_lane[4] = {L.g == L.c, L.g + 4 == L.c, L.g + 8 == L.c, L.g + 12 == L.c};
     double J = 0.0;
+    // The stage costs of the whole horizon are kept in LDS (in the space of the backward sweep's 16-step blocks, free
+    // here) and summed at the end, so that the rounds of 16 steps follow each other without a barrier; a horizon too
+    // long for that space is summed round by round.
+    double* const stage = &S.zb[0][0];
+    static_assert(sizeof(S.zb) + sizeof(S.lxb) == 2 * LA * (LN + 1) * sizeof(double), "");
+    const bool all_in_lds = T + LA <= 2 * LA * (LN + 1);
     for (int t0 = 0; t0 < T; t0 += LA) {
         const int st = t0 + L.c < T ? t0 + L.c : T - 1; // (columns beyond the last step repeat it; they are not added)
         d4 xd[2][1], ud[1][1], ax[2][1], au[1][1], sx[1][1], su[1][1];
@@ -1567,11 +1573,21 @@ __device__ double large_traj_cost(const LargeP& P, WaveMem& S, const double* xs,
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (diag_lane[r])
-                S.J[L.c] = PATH ? sx[0][0][r] + su[0][0][r] : sx[0][0][r] * 0.5 + su[0][0][r] * 0.5;
+                (all_in_lds ? stage[t0 + L.c] : S.J[L.c]) =
+                    PATH ? sx[0][0][r] + su[0][0][r] : sx[0][0][r] * 0.5 + su[0][0][r] * 0.5;
+        if (!all_in_lds) {
+            wave_sync();
+            const int nc = T - t0 < LA ? T - t0 : LA;
+            for (int c = 0; c < nc; ++c)
+                J = J + S.J[c];
+            wave_sync();
+        }
+    }
+    if (all_in_lds) { // the sum over t, in the order of t, once all stage costs are there
         wave_sync();
-        const int nc = T - t0 < LA ? T - t0 : LA;
-        for (int c = 0; c < nc; ++c)
-            J = J + S.J[c];
+#pragma unroll 8
+        for (int t = 0; t < T; ++t)
+            J = J + stage[t];
         wave_sync();
     }
     {
