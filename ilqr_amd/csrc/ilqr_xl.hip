@@ -67,6 +67,7 @@ __device__ __forceinline__ XlP xl_for_problem(const XlP& P, int64_t b)
 
 struct XlQP {
     int max_iter;
+    int n_exhaust; // number of step reductions after which step < min_step (host-simulated)
     double min_grad, min_rel, step_dec, min_step, armijo;
 };
 
@@ -411,6 +412,60 @@ __device__ __forceinline__ double xl_value(const XlBw& W, double* xq, int lane, 
     return xg + 0.5 * tot;
 }
 
+// Armijo loop, proof of exhaustion.  Near a solution the reference's backtracking loop (ilqr_boxQP.py:151-159) often
+// runs until the step falls below min_step: the search direction is tiny, every candidate's objective equals the old
+// one up to rounding, and (vc - old) / (sdotg + 1e-10) stays below the Armijo constant because of the 1e-10.  Before
+// 64 more literal trips are evaluated the wavefront tries to PROVE that every trip from step size `st` on continues:
+//   |xc_i - x_i| <= E_i = (1 + 1e-7) st |s_i| + 1.2e-16 |x_i|   (two roundings; clamping only shortens it)
+//   exact objective v:  |v(xc) - v(x)| <= sum_i E_i G_i + 1/2 sum_ij E_i |H_ij| E_j,   with
+//       G_i = 1.01 (|grad_i| + 2.2e-15 (|g_i| + sum_j |H_ij| |x_j|) + 1/2 sum_j |H_ij - H_ji| |x_j|)
+//       (computed gradient + the rounding error of its 16-term chain + the asymmetry of the computed Q_uu)
+//   computed objective (a 16-term chain, 16 chains of 16 terms, a chain over their results, one add):
+//       |V(z) - v(z)| <= 6e-15 A,   A = sum_i X_i |g_i| + sum_ij X_i |H_ij| X_j,  X_i = |x_i| + E_i >= |z_i|
+//   hence |vc - old| <= NUM = 1.001 (sum E G + 1/2 E|H|E + 12e-15 A) + 1e-200, and the computed slope satisfies
+//   |sdotg| <= S = 1.001 sum_i E_i |grad_i|, so the denominator is >= 0.999 (1e-10 - S).
+// If S < 1e-10 and NUM < armijo * 0.999 (1e-10 - S), the quotient is below armijo at this step size, and -- all
+// bounds grow with st -- at every smaller one: the loop ends at trip n_exhaust with result 2 and that trip's
+// candidate.  Any NaN or infinity makes a comparison false (no proof, literal evaluation).  The bounds are generous
+// by the factors shown.  Lane a < 16 forms the terms of variable a (Hr: its row of Q_uu, gl and grad: its entries of
+// g and of the computed gradient); x and the search direction are replicated.
+__device__ __forceinline__ bool xl_armijo_exhausts(const XlBw& W, const double (&Hr)[XM], int lane, double gl,
+                                                   double grad, const double (&x)[XM], const double (&srch)[XM],
+                                                   double st, double armijo)
+{
+    const int la = lane & (XM - 1);
+    double hax = 0.0, asy = 0.0, hE = 0.0, hX = 0.0, Ea = 0.0, Xa = 0.0;
+#pragma unroll
+    for (int j = 0; j < XM; ++j) {
+        const double axj = fabs(x[j]);
+        const double Ej = 1.0000001 * st * fabs(srch[j]) + 1.2e-16 * axj;
+        const double Xj = axj + Ej;
+        const double h = fabs(Hr[j]);
+        hax = fma(h, axj, hax);
+        hE = fma(h, Ej, hE);
+        hX = fma(h, Xj, hX);
+        asy = fma(fabs(Hr[j] - W.H[j * LDM + la]), axj, asy);
+        Ea = lane == j ? Ej : Ea;
+        Xa = lane == j ? Xj : Xa;
+    }
+    const bool own = lane < XM;
+    const double ag = fabs(gl), agr = fabs(grad);
+    const double G = 1.01 * (agr + 2.2e-15 * (ag + hax) + 0.5 * asy);
+    const double t1 = own ? Ea * G + 0.5 * (Ea * hE) : 0.0;
+    const double t2 = own ? Xa * ag + Xa * hX : 0.0;
+    const double t3 = own ? Ea * agr : 0.0;
+    double d1 = 0.0, A = 0.0, Ss = 0.0;
+#pragma unroll
+    for (int a = 0; a < XM; ++a) {
+        d1 += xl_rl(t1, a);
+        A += xl_rl(t2, a);
+        Ss += xl_rl(t3, a);
+    }
+    const double NUM = 1.001 * (d1 + 12e-15 * A) + 1e-200;
+    const double S = 1.001 * Ss;
+    return xl_uni((S < 1e-10) && (armijo > 0.0) && (NUM < armijo * (0.999 * (1e-10 - S))));
+}
+
 // np.all(np.linalg.eigvals(Q_uu) > 0) else break; R_Q_uu = cholesky(Q_uu); k = cho_solve(R_Q_uu, Q_u) (the warm
 // start, positive sign as the reference has it); boxQP(Q_uu, Q_u, lower - u, upper - u, k) (ilqr_boxQP.py:9-186);
 // K[free] = -cho_solve(H_ff, Q_ux[free]); Delta_J   (ilqr_core.py:134-176).
@@ -587,7 +642,18 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
         XP_T(a0);
         double base = 1.0;
         int t0 = 0;
+        bool proven = false;
         for (;;) {
+            if (proven) { // every trip from t0 on continues: the loop ends at trip n_exhaust with that trip's candidate
+                const double se = W.steps[O.n_exhaust];
+#pragma unroll
+                for (int a = 0; a < XM; ++a)
+                    x[a] = xl_clamp(lov[a], hiv[a], x[a] + se * srch[a]);
+                value = xl_value(W, xq, lane, x);
+                result = 2;
+                out.n_backtrack += O.n_exhaust;
+                break;
+            }
             double mine;
             if (t0 + 64 <= XTAB) {
                 mine = W.steps[t0 + lane];
@@ -627,6 +693,9 @@ __device__ __forceinline__ XlQpOut xl_qp_phase(XlBw& W, int p, const XlQP& O, in
                 break;
             }
             t0 += 64;
+            // (the same proof for the trips from t0 on, before 64 more of them are evaluated)
+            if (t0 <= O.n_exhaust && O.n_exhaust < XTAB)
+                proven = xl_armijo_exhausts(W, Hr, lane, gl, grad, x, srch, W.steps[t0], O.armijo);
         }
         XP_T(a1);
         XP_ADD(8, a0, a1);
@@ -1630,6 +1699,7 @@ int xl_qp(const ilqr_opts* o, XlQP& q)
     if (n > 65536)
         return ILQR_ERR_UNSUPPORTED;
     q.max_iter = o->qp_max_iter;
+    q.n_exhaust = n;
     q.min_grad = o->qp_min_grad;
     q.min_rel = o->qp_min_rel_improve;
     q.step_dec = o->qp_step_dec;
