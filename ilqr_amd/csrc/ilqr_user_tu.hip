@@ -629,13 +629,35 @@ struct GCost { // QRCost (ilqr/ilqr_cost.py:490-530) or PathQRCost (:635-770)
     int path;
     int64_t gsx, gsu;
 };
-__device__ __forceinline__ const double* ggoal_x(const GCost& C, int64_t gp, int t)
+// The goal of problem gp at time step t, into registers.  (Two separate loads, not one load through a selected
+// pointer: the shared goal lives in LDS with the cost, a path or a goal per problem in global memory, and a pointer
+// that may be either is a generic pointer -- its loads are slower and every one of them was waited for at once.)
+typedef const double __attribute__((address_space(1))) * GGlobalIn;
+__device__ __forceinline__ void ggoal_x(const GCost& C, int64_t gp, int t, double (&xg)[UN])
 {
-    return C.x_path != nullptr ? C.x_path + gp * C.gsx + (C.path ? (int64_t)t * UN : 0) : C.xg;
+    if (C.x_path != nullptr) {
+        const GGlobalIn q = (GGlobalIn)(C.x_path + gp * C.gsx + (C.path ? (int64_t)t * UN : 0));
+#pragma unroll
+        for (int a = 0; a < UN; ++a)
+            xg[a] = q[a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < UN; ++a)
+            xg[a] = C.xg[a];
+    }
 }
-__device__ __forceinline__ const double* ggoal_u(const GCost& C, int64_t gp, int t)
+__device__ __forceinline__ void ggoal_u(const GCost& C, int64_t gp, int t, double (&ug)[UM])
 {
-    return C.u_path != nullptr ? C.u_path + gp * C.gsu + (C.path ? (int64_t)t * UM : 0) : C.ug;
+    if (C.u_path != nullptr) {
+        const GGlobalIn q = (GGlobalIn)(C.u_path + gp * C.gsu + (C.path ? (int64_t)t * UM : 0));
+#pragma unroll
+        for (int a = 0; a < UM; ++a)
+            ug[a] = q[a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < UM; ++a)
+            ug[a] = C.ug[a];
+    }
 }
 struct GBounds {
     double lo[UM], hi[UM];
@@ -659,8 +681,8 @@ __device__ __forceinline__ void gstore(double* base, int64_t row0, int64_t b, co
 // QRCost.l, ilqr_cost.py:532-553 (the value carries the 1/2 its gradients lack)
 __device__ inline double gcost_l(const GCost& C, const double* x, const double* u, int64_t gp, int t, bool terminal)
 {
-    double xd[UN], ud[UM];
-    const double* xg = ggoal_x(C, gp, t);
+    double xd[UN], ud[UM], xg[UN];
+    ggoal_x(C, gp, t, xg);
     for (int a = 0; a < UN; ++a)
         xd[a] = x[a] - xg[a];
     double sx = qpg_quad(UN, xd, terminal ? C.Qt : C.Q);
@@ -668,7 +690,8 @@ __device__ inline double gcost_l(const GCost& C, const double* x, const double* 
         sx = sx * 0.5;
     if (terminal)
         return sx;
-    const double* ug = ggoal_u(C, gp, t);
+    double ug[UM];
+    ggoal_u(C, gp, t, ug);
     for (int a = 0; a < UM; ++a)
         ud[a] = u[a] - ug[a];
     double su = qpg_quad(UM, ud, C.R);
@@ -680,8 +703,8 @@ __device__ inline double gcost_l(const GCost& C, const double* x, const double* 
 __device__ inline void gcost_lx(const GCost& C, const double* x, int64_t gp, int t, bool terminal, double* out)
 {
     const double* Qm = terminal ? C.Qt : C.Q;
-    const double* xg = ggoal_x(C, gp, t);
-    double xd[UN];
+    double xd[UN], xg[UN];
+    ggoal_x(C, gp, t, xg);
     for (int a = 0; a < UN; ++a)
         xd[a] = x[a] - xg[a];
     for (int j = 0; j < UN; ++j) {
@@ -710,8 +733,8 @@ __device__ int gbw_step(const UParams& P, const GCost& C, const QPOptsP& QO, con
     ilqr_user_jac(P.p, x, u, fx, fu);
     gcost_lx(C, x, gp, t, false, lx);
     {   // l_u = u_diff^T (R + R^T), ilqr_cost.py:571-587
-        double ud[m];
-        const double* ug = ggoal_u(C, gp, t);
+        double ud[m], ug[UM];
+        ggoal_u(C, gp, t, ug);
         for (int a = 0; a < m; ++a)
             ud[a] = u[a] - ug[a];
         for (int j = 0; j < m; ++j) {
