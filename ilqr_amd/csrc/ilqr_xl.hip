@@ -124,6 +124,7 @@ struct XlMem {
     double res_d[4];   // wave 0 -> workgroup: value hand-overs (boxQP: candidate value; sweep: Delta_J1, Delta_J2)
     int res_i[8];      // ... and integers (flag of a backward step; counters of a sweep)
     int next;          // the problem taken from the queue
+    int arrived;       // wavefronts 1..3 that have written their rows of M1, counted up through a sweep
 };
 
 static_assert(sizeof(XlMem) <= 160 * 1024, "one problem's matrices must fit the LDS of a CU");
@@ -861,6 +862,9 @@ __device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem&
     }
     if (wave >= 1)
         xl_stage_step<PATH>(P, W, xs, us, T - 1, wave - 1, lane);
+    if (tid == 0)
+        S.arrived = 0;
+    int n_arrivals = 0; // (steps this sweep has been through)
     double dJ1 = 0.0, dJ2 = 0.0; // (wave 0's; handed to the workgroup at the end)
     int qp_iter = 0, qp_bt = 0, n_cl = 0;
     o.stopped_at = -1;
@@ -893,17 +897,11 @@ __device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem&
     c = lane & 15
         XL_FRESH_LANE();
         XP_T(c0);
-        // -- (1) M1 = f_x^T V_xx, M2 = f_u^T (V_xx + mu I); Q_x, Q_u   (:200-212)
-        for (int q = wave; q < NT * NT + NT; q += 4) {
-            if (q < NT * NT) {
-                const int it = q / NT, jt = q - it * NT;
-                xl_tile_store(W.M1, LDN, n, n, it, jt, xl_tile<true, false>(W.fx, LDN, W.Vxx, LDN, it, jt, KN, g, c), g, c);
-            } else {
-                const int jt = q - NT * NT;
-                xl_tile_store(W.M2, LDN, m, n, 0, jt,
-                              xl_tile<true, false, true>(W.fu, LDM, W.Vxx, LDN, 0, jt, KN, g, c, mu, n), g, c);
-            }
-        }
+        // -- (1) M2 = f_u^T (V_xx + mu I); Q_x, Q_u   (:200-212; M1 = f_x^T V_xx, which only Q_xx needs, is formed in
+        // phase (3) beside the boxQP)
+        for (int jt = wave; jt < NT; jt += 4)
+            xl_tile_store(W.M2, LDN, m, n, 0, jt,
+                          xl_tile<true, false, true>(W.fu, LDM, W.Vxx, LDN, 0, jt, KN, g, c, mu, n), g, c);
         // Q_x = l_x + f_x^T V_x, Q_u = l_u + f_u^T V_x (:206-207): lane = entry, the chain over the states 16 terms at a
         // time (operands beyond n are zeros: fma(0, 0, s) == s)
         if (wave == 3 || wave == 2) {
@@ -976,6 +974,24 @@ __device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem&
             XP_ADD(12, c2, c2c);
         } else {
             const int hw = wave - 1;
+            // M1 = f_x^T V_xx (:208): this wavefront forms the row blocks hw and hw + 3 -- they read the column blocks
+            // of f_x that are its own (it rewrites them for the next step further down) -- and Q_xx = l_xx + M1 f_x
+            // below needs every row block: the three wavefronts meet at a counter in LDS in between (wavefront 0 is
+            // busy with the boxQP and takes no part, so it is not a workgroup barrier).
+            for (int bs = 0; bs < 2; ++bs) {
+                const int it = hw + 3 * bs;
+                if (it < NT)
+                    for (int jt = 0; jt < NT; ++jt)
+                        xl_tile_store(W.M1, LDN, n, n, it, jt,
+                                      xl_tile<true, false>(W.fx, LDN, W.Vxx, LDN, it, jt, KN, g, c), g, c);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_fetch_add(&S.arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S.arrived, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_WORKGROUP)) < 3 * (n_arrivals + 1))
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int bs = 0; bs < 2; ++bs)
 #pragma unroll
@@ -998,6 +1014,7 @@ __device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem&
             if (i > 0)
                 xl_stage_step<PATH>(P, W, xs, us, i - 1, hw, lane);
         }
+        ++n_arrivals;
         __syncthreads();
         XP_T(c3);
         XP_ADD(2, c2, c3);
