@@ -1061,9 +1061,38 @@ __device__ __forceinline__ void xl_backward(const XlP& P, const XlQP& QO, XlMem&
                 for (int it = 0; it < 4; ++it) {
                     const int jt = hw + 3 * bs;
                     if (jt < NT && it < NT) {
-                        const d4 t1 = xl_tile<false, false>(W.T1, LDM, W.Kl, LDN, it, jt, KM, g, c);
-                        const d4 t2 = xl_tile<true, false>(W.Kl, LDN, W.Qux, LDN, it, jt, KM, g, c);
-                        const d4 t3 = xl_tile<true, false>(W.Qux, LDN, W.Kl, LDN, it, jt, KM, g, c);
+                        // the three products of a tile, (K^T Q_uu) K, K^T Q_ux and Q_ux^T K: their operands -- four
+                        // k-blocks each, rows beyond m are the zeros of the invariant -- are all requested before the
+                        // first MFMA, so that the tile waits for LDS once instead of three times
+                        d4 t1 = d4{0.0, 0.0, 0.0, 0.0}, t2 = t1, t3 = t1;
+                        {
+                            const int ii = 16 * it + c, jj = 16 * jt + c;
+                            const double* pa1 = W.T1 + ii * LDM + g;
+                            const double* pkj = W.Kl + g * LDN + jj;
+                            const double* pki = W.Kl + g * LDN + ii;
+                            const double* pqj = W.Qux + g * LDN + jj;
+                            const double* pqi = W.Qux + g * LDN + ii;
+                            double a1[4], kj[4], ki[4], qj[4], qi[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                a1[u] = pa1[4 * u];
+                                kj[u] = pkj[4 * u * LDN];
+                                ki[u] = pki[4 * u * LDN];
+                                qj[u] = pqj[4 * u * LDN];
+                                qi[u] = pqi[4 * u * LDN];
+                            }
+                            XL_PIN4(a1);
+                            XL_PIN4(kj);
+                            XL_PIN4(ki);
+                            XL_PIN4(qj);
+                            XL_PIN4(qi);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                t1 = xl_mfma(a1[u], kj[u], t1);
+                                t2 = xl_mfma(ki[u], qj[u], t2);
+                                t3 = xl_mfma(qi[u], kj[u], t3);
+                            }
+                        }
                         d4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
