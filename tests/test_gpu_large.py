@@ -119,6 +119,21 @@ def test_large_solve_shortest_horizons(hip, T):
         assert eq(out[key].cpu().numpy(), ref[key]), key
 
 
+def test_large_solve_long_horizon(hip):
+    """A horizon longer than the LDS space in which the cost of a stored trajectory keeps its stage costs (1040 steps):
+    the costs are then summed round by round.  Whole solves, every output against the oracle."""
+    T, B = 1100, 5
+    Mo, M = models(hip, T)
+    x0, us0 = co.synthetic_batch(B, T=T, seed_x=91, seed_u=92)
+    ref = co.solve(Mo, co.Opts(max_iter=5), x0, us0, nthreads=5)
+    out = hip.large_solve(M, hip.Opts(max_iter=5), dev(x0), dev(us0))
+    torch.cuda.synchronize()
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    for key in ("J", "mu", "delta", "xs", "us", "k", "K"):
+        assert eq(out[key].cpu().numpy(), ref[key]), key
+
+
 def test_large_solve_more_problems_than_wavefronts(hip):
     """The solve kernel keeps one workgroup per CU resident and hands problems out from a queue: with more
     problems than the chip has wavefront slots every wavefront solves several, one after the other, and
